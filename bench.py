@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: audio frames/s (and per-frame logit max-abs-err vs the CPU
+reference) on the named frame shape.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload = BASELINE configs[1]): per GPU, B=256 utterances x 10 s of synthetic
+16 kHz audio, 25 ms / 10 ms frames, 64-bin log-mel (Hamming) + PyanNet2 classifier; a "step" is
+one pass of the whole hot path (uvad_forward: PCM resident in HBM -> per-frame logits in HBM) over
+that batch.  N GPUs = N independent shards of 256 utterances (weak scaling, no data-path
+collective; utterance ids are disjoint across ranks).  value = frames all ranks processed / max
+over ranks of the time for exactly K steps bracketed by barrier + synchronize.
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel (by HIP-event time inside the timed region), achieved
+                  algorithmic FLOP/s or B/s over its average launch duration vs the gfx950 peak.
+  stages       -- per-stage ms and roofline fractions (feature stage: HBM; classifier: fp32 MFMA).
+  cpu_baseline -- oracle/torch_ref (torch CPU operators, same op sequence as the reference) timed on
+                  this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+  max_abs_logit_err -- GPU logits vs that CPU reference on the sample's first utterances.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* peak
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+B_PER_GPU, SECONDS, N_MELS = 256, 10.0, 64
+
+
+def classifier_flops_per_frame(F, H=128, L=4, D=2, lin=128, lin_layers=2):
+    proj = 2 * (D * 4 * H * F + (L - 1) * D * 4 * H * (H * D))
+    rec = 2 * (L * D * 4 * H * H)
+    head = 2 * ((H * D) * lin + (lin_layers - 1) * lin * lin + lin)
+    return proj, rec, head
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU (default = BASELINE cfg 2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import uvad_amd
+    from uvad_amd import dist as udist
+    from uvad_amd.synth import seed_weights, synth_pcm_device
+
+    rank, local_rank, world = udist.init()
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    B, S = args.batch, int(SECONDS * 16000)
+    model = uvad_amd.PyanNet2(encoding_dim=N_MELS)
+    model.build()
+    seed_weights(model, 1234, 4.0)
+    model.attach_fbank(uvad_amd.FbankConfig(num_filters=N_MELS, window_type="hamming"))
+    model = model.to(dev).eval()
+    rt = model.runtime(dev)
+    pcm = synth_pcm_device(B, S, seed=42, device=dev, first=rank * B)   # disjoint utterance ids per rank
+    T = rt.num_frames(S)
+
+    for _ in range(args.warmup):
+        rt.forward(pcm, want_probs=False)
+    rt.set_timing(True)
+    acc = {"fbank": 0.0, "proj": 0.0, "recurrent": 0.0, "head": 0.0, "total": 0.0}
+    torch.cuda.synchronize(dev)
+    udist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits, _ = rt.forward(pcm, want_probs=False)
+        for k, v in rt.timing_ms().items():     # waits on this step's last event only
+            acc[k] += v
+    torch.cuda.synchronize(dev)
+    udist.barrier()
+    elapsed = time.perf_counter() - t0
+    rt.set_timing(False)
+    elapsed = udist.max_over_ranks(elapsed, device=dev if world > 1 else None)
+
+    frames_total = world * B * T * args.steps
+    value = frames_total / elapsed
+    ms = {k: v / args.steps for k, v in acc.items()}
+    proj_f, rec_f, head_f = classifier_flops_per_frame(N_MELS)
+    frames_step = B * T
+    stage = {
+        "fbank": {"ms": ms["fbank"], "bound": "hbm", "achieved_GBs": frames_step * (640 + 4 * N_MELS) / (ms["fbank"] * 1e-3) / 1e9 if ms["fbank"] > 0 else None},
+        "proj": {"ms": ms["proj"], "bound": "mfma", "achieved_TFLOPs": frames_step * proj_f / (ms["proj"] * 1e-3) / 1e12},
+        "recurrent": {"ms": ms["recurrent"], "bound": "mfma", "achieved_TFLOPs": frames_step * rec_f / (ms["recurrent"] * 1e-3) / 1e12},
+        "head": {"ms": ms["head"], "bound": "mfma", "achieved_TFLOPs": frames_step * head_f / (ms["head"] * 1e-3) / 1e12},
+    }
+    stage["fbank"]["frac"] = stage["fbank"]["achieved_GBs"] / PEAK_HBM_GBS if stage["fbank"]["achieved_GBs"] else None
+    for k in ("proj", "recurrent", "head"):
+        stage[k]["frac"] = stage[k]["achieved_TFLOPs"] / PEAK_F32_MFMA_TFLOPS
+    # dominant kernel: the recurrent kernel (one launch per layer) or the projection GEMM (one per layer)
+    L = 4
+    if ms["recurrent"] >= ms["proj"]:
+        kern, flops_launch, dur_ms = "lstm_rec_kernel<128>", frames_step * rec_f / L, ms["recurrent"] / L
+    else:
+        kern, flops_launch, dur_ms = "gemm_f32_kernel", frames_step * proj_f / L, ms["proj"] / L
+    achieved = flops_launch / (dur_ms * 1e-3) / 1e12
+    roofline = {"kernel": kern, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": dur_ms,
+                "flops_per_launch": flops_launch}
+
+    out = {
+        "metric": "audio frames/sec (log-mel + PyanNet2 VAD forward); per-frame logit max-abs-err vs CPU ref",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"batch={B} x 10 s synthetic 16 kHz per GPU, 25 ms/10 ms frames, 64-bin log-mel (hamming) + "
+                               "PyanNet2 4xBiLSTM(128)+2xFC classifier (BASELINE configs[1])",
+                   "utterances_per_gpu": B, "frames_per_utterance": T, "n_mels": N_MELS, "sharding": f"utterance-shard x{world}"},
+        "roofline": roofline, "stages": stage,
+        "classifier_frac_of_f32_mfma_peak": frames_step * (proj_f + rec_f + head_f) / ((ms["total"] - ms["fbank"]) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out.update(cpu_baseline_and_error(model, rt, pcm, dev))
+    if rank == 0:
+        print(json.dumps(out))
+    udist.barrier()
+
+
+def cpu_baseline_and_error(model, rt, pcm, dev):
+    """Reference CPU path (oracle/torch_ref: the reference's operator sequence on torch CPU ops) on a
+    bounded sample of the SAME utterances and weights, all host cores; plus logit error GPU vs CPU."""
+    from oracle import torch_ref as tr
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    F = N_MELS
+    cpu = tr.TorchPyanNet2(F)
+    cpu.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    win, mel = tr.make_window("hamming", 400), tr.make_mel(F)
+
+    def run(x):
+        feats = tr.torch_fbank(x, win, mel)
+        return cpu(feats)[0]
+
+    x_all = pcm.cpu()
+    run(x_all[:4])                                  # warm-up
+    t = time.perf_counter(); run(x_all[:16]); dt16 = time.perf_counter() - t
+    nb = int(max(16, min(x_all.shape[0], 16 * 15.0 / max(dt16, 1e-3))))   # ~15 s of CPU work
+    t = time.perf_counter(); ref = run(x_all[:nb]); dt = time.perf_counter() - t
+    T = ref.shape[1]
+    gl, _ = rt.forward(pcm[:nb].contiguous(), want_probs=False)
+    err = float((gl.cpu() - ref).abs().max())
+    return {"cpu_baseline": {"value": nb * T / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+                             "sample": f"first {nb} of the {x_all.shape[0]} utterances x 10 s, fbank + classifier, "
+                                       f"torch {torch.__version__} CPU ops, {cores} threads, 1 rep ({dt:.1f} s)"},
+            "max_abs_logit_err": err, "logit_err_sample": f"{nb} utterances x {T} frames vs torch-CPU reference path"}
+
+
+if __name__ == "__main__":
+    main()

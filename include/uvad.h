@@ -1,0 +1,153 @@
+/*
+ * uvad.h -- C ABI of libuvad.so: MI355X (gfx950) voice-activity hot path.
+ *
+ *   16 kHz PCM --fbank--> log-mel (B,T,F) --classify--> per-frame logit / probability
+ *
+ * The reference (arnavsshah/universal-voice-activity-detection) is pure Python and has no
+ * FFI for this path; its boundary is a set of torch.nn.Module / lhotse call contracts.
+ * Each entry point below names the reference interface it stands behind (paths relative to
+ * the reference root).  The Python host in universal-voice-activity-detection_amd/ binds
+ * these with ctypes (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - return 0 on success, negative on error: UVAD_E_ARG bad argument, UVAD_E_HIP HIP runtime
+ *     error (no GPU, launch failure), UVAD_E_STATE wrong call order (not finalized ...),
+ *     UVAD_E_WORKSPACE workspace too small, UVAD_E_UNSUPPORTED configuration outside what the
+ *     kernels implement.  uvad_last_error() gives the text.
+ *   - every pointer named d_* is a DEVICE pointer owned by the caller; the library never
+ *     allocates or frees caller tensors.  It owns only the weights / tables inside uvad_ctx.
+ *   - compute calls are ASYNCHRONOUS on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and perform no allocation or synchronisation => hipGraph-capturable.
+ *   - one ctx per (device, model); a ctx is NOT thread-safe (the reference drives the model
+ *     from a single thread: Trainer(devices=1), src/scripts/predict.py:79-85).
+ *   - there is NO CPU fallback: on a machine without a gfx950 device uvad_create fails.
+ */
+#ifndef UVAD_H
+#define UVAD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UVAD_OK             0
+#define UVAD_E_ARG         -1
+#define UVAD_E_HIP         -2
+#define UVAD_E_STATE       -3
+#define UVAD_E_WORKSPACE   -4
+#define UVAD_E_UNSUPPORTED -5
+
+#define UVAD_ABI_VERSION 1
+
+typedef struct uvad_ctx uvad_ctx; /* opaque */
+
+/* Feature-stage configuration = lhotse FbankConfig as constructed at
+ * src/datasets/ami/utils.py:153 and src/utils/helper.py:120 (all defaults but sampling_rate). */
+typedef struct {
+    int sample_rate;   /* 16000 */
+    int frame_len;     /* samples per frame: 400 (25 ms) */
+    int frame_shift;   /* hop: 160 (10 ms) */
+    int n_fft;         /* 512 (next power of two of frame_len); only 512 is implemented */
+    int n_mels;        /* 80 in the reference (config/config.py:33), 64 in BASELINE cfg 2 */
+    float preemph;     /* 0.97 */
+    float low_hz;      /* informational (the mel matrix is uploaded by uvad_set_tables) */
+    float high_hz;     /* informational */
+    float log_floor;   /* FLT_EPSILON */
+    int remove_dc;     /* 1 */
+    int snip_edges;    /* 0 (reflect-padded, T = (S + shift/2) / shift) */
+} uvad_fbank_cfg;
+
+/* Classifier configuration = constructor arguments of PyanNet2,
+ * src/models/segmentation/PyanNet2.py:60-90 (LSTM_DEFAULTS / LINEAR_DEFAULTS / encoding_dim). */
+typedef struct {
+    int in_dim;        /* encoding_dim */
+    int hidden;        /* lstm.hidden_size: 128 (64 also implemented) */
+    int num_layers;    /* lstm.num_layers: 4 */
+    int bidirectional; /* lstm.bidirectional: 1 */
+    int lin_hidden;    /* linear.hidden_size: 128 */
+    int lin_layers;    /* linear.num_layers: 2 */
+    float leaky_slope; /* F.leaky_relu default 0.01 (PyanNet2.py:185) */
+} uvad_model_cfg;
+
+/* ABI version of the loaded library (== UVAD_ABI_VERSION of the header it was built from). */
+int uvad_abi_version(void);
+
+/* Replaces: PyanNet2.__init__/build (PyanNet2.py:69-152) + Fbank(FbankConfig(...)) construction
+ * (ami/utils.py:153).  Either cfg may be NULL if that stage is not used. */
+int uvad_create(int device, const uvad_fbank_cfg *fb, const uvad_model_cfg *model, uvad_ctx **out);
+
+/* Host tables for the feature stage: window[frame_len]; mel[n_mels][n_fft/2+1] row-major
+ * (any banded non-negative matrix; the library converts it to per-filter (start,len,weights)).
+ * Replaces the window / filterbank buffers lhotse builds inside Fbank (third party). */
+int uvad_set_tables(uvad_ctx *, const float *window, const float *mel);
+
+/* One tensor of the PyanNet2 state_dict, by its torch key ("lstm.weight_ih_l0_reverse",
+ * "linear.0.weight", "classifier.bias", ...; an optional "model." Lightning prefix is stripped),
+ * host pointer, row-major f32.  Replaces nn.Module.load_state_dict / VadModel.load_from_checkpoint
+ * (src/scripts/predict.py:77). */
+int uvad_set_weight(uvad_ctx *, const char *torch_key, const float *host, const int64_t *shape, int ndim);
+
+/* Checks that every tensor is present, repacks into kernel layouts and uploads. */
+int uvad_finalize(uvad_ctx *);
+
+/* T for S samples (lhotse framing; data/test_data.py:23 pins T = S/160 for 5 s cuts). */
+int64_t uvad_num_frames(const uvad_ctx *, int64_t S);
+
+/* Bytes of caller-provided device workspace uvad_classify / uvad_forward need for B sequences of
+ * T frames (uvad_forward: pass T = uvad_num_frames(S)). */
+size_t uvad_workspace_bytes(const uvad_ctx *, int B, int64_t T);
+
+/* Replaces: Fbank.extract_batch (lhotse; call sites ami/utils.py:157-163, helper.py:122-130).
+ * d_pcm [B][S] f32 in [-1,1]  ->  d_feats [B][T][n_mels] f32. */
+int uvad_fbank(uvad_ctx *, const float *d_pcm, int B, int64_t S, float *d_feats, void *stream);
+
+/* Same with int16 PCM (wav ingest; halves the HBM read).  Samples are scaled by 1/32768. */
+int uvad_fbank_i16(uvad_ctx *, const int16_t *d_pcm, int B, int64_t S, float *d_feats, void *stream);
+
+/* Replaces: PyanNet2.forward (PyanNet2.py:154-187) = VadModel.forward (vad_engine.py:69-80).
+ * d_feats [B][T][in_dim] -> d_logits [B][T] (pre-sigmoid, may be NULL) and d_probs [B][T]
+ * (what forward returns, viewed as (B,T,1); may be NULL). */
+int uvad_classify(uvad_ctx *, const float *d_feats, int B, int T, float *d_logits, float *d_probs,
+                  void *d_workspace, size_t ws_bytes, void *stream);
+
+/* uvad_fbank + uvad_classify without returning the features (they stay in the workspace). */
+int uvad_forward(uvad_ctx *, const float *d_pcm, int B, int64_t S, float *d_logits, float *d_probs,
+                 void *d_workspace, size_t ws_bytes, void *stream);
+
+/* Debug / parity taps: copy of the last LSTM layer output [B][T][hidden*dirs] and of the last
+ * feed-forward activation [B][T][lin_hidden] from the most recent uvad_classify on this
+ * workspace (async on stream).  Either pointer may be NULL. */
+int uvad_get_taps(uvad_ctx *, int B, int T, float *d_lstm_out, float *d_lin_out,
+                  const void *d_workspace, void *stream);
+
+/* Streaming (BASELINE cfg 5; the reference has no streaming mode): causal model
+ * (bidirectional = 0), carried state.  d_state holds, per stream, the PCM tail needed by the next
+ * frame and (h, c) of every layer; uvad_stream_state_bytes gives its size for B streams; zero it
+ * to start a stream.  d_pcm_chunk [B][chunk] with chunk a multiple of frame_shift produces
+ * chunk/frame_shift new logits per stream in d_logits [B][chunk/frame_shift]. */
+size_t uvad_stream_state_bytes(const uvad_ctx *, int B);
+int uvad_stream_step(uvad_ctx *, const float *d_pcm_chunk, int B, int chunk, void *d_state,
+                     float *d_logits, void *d_workspace, size_t ws_bytes, void *stream);
+
+/* Replaces: median_filter (src/utils/helper.py:66-97) as used by VadModel.predict_step
+ * (vad_engine.py:204-211): threshold 0.5 then odd `kernel`-tap median, zero padded edges.
+ * d_probs [B][T] -> d_labels [B][T] uint8 (0/1). */
+int uvad_median_filter(uvad_ctx *, const float *d_probs, int B, int T, int kernel, uint8_t *d_labels,
+                       void *stream);
+
+/* Per-stage device timing of the most recent uvad_forward/uvad_classify made with timing enabled
+ * (uvad_set_timing(ctx, 1) inserts hipEvents on the caller's stream; not graph-capturable while
+ * enabled).  ms[0..4] = fbank, input projections, recurrences, feed-forward+classifier, total.
+ * Synchronises on the recorded events. */
+int uvad_set_timing(uvad_ctx *, int enabled);
+int uvad_get_timing(uvad_ctx *, float ms[5]);
+
+const char *uvad_last_error(const uvad_ctx *);
+void uvad_destroy(uvad_ctx *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UVAD_H */

@@ -1,0 +1,12 @@
+"""MI355X-native voice-activity inference path: fused log-mel front end + PyanNet2 classifier
+as hand-written gfx950 HIP kernels behind a C ABI (libuvad.so), with a Python host that mirrors
+the reference's ``src.models`` / ``src.engines`` / ``config`` / ``main`` surface."""
+from .config import ConfigDict, load_config
+from .engine import VadModel
+from .features import Fbank, FbankConfig, make_mel_matrix, make_window
+from .models import PyanNet, PyanNet2
+from .postprocess import labels_to_intervals, median_filter, median_window
+from .scripts import predict_vad
+
+__all__ = ["ConfigDict", "load_config", "VadModel", "Fbank", "FbankConfig", "make_mel_matrix", "make_window",
+           "PyanNet", "PyanNet2", "labels_to_intervals", "median_filter", "median_window", "predict_vad"]

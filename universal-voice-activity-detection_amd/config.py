@@ -1,0 +1,63 @@
+"""``load_config()`` with the reference's key names (config/config.py:4-438) for the inference
+path.  The reference returns an ``ml_collections.ConfigDict`` (not installed here); ``ConfigDict``
+below gives the same attribute + mapping access, including ``**config`` splatting (main.py:34-44).
+Corpus / training / W&B keys of the reference are out of scope and omitted; a manifest-free
+``input`` block (synthetic signal or wav files) replaces the lhotse manifests on cluster paths."""
+import os
+
+
+class ConfigDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def load_config() -> ConfigDict:
+    cfg = ConfigDict()
+
+    cfg.task = "run"            # only "run" is in scope (reference: wer/download/prepare/... are data plumbing)
+    cfg.function = "predict"    # only "predict" is in scope
+
+    cfg.seed = 42
+    cfg.device = "gpu"          # the HIP path needs a GPU; "cpu" raises (no fallback)
+    cfg.num_devices = 1
+    cfg.distributed_training = False
+
+    cfg.feature_extractor = "fbank"   # the log-mel path; sincnet / wav2vec2 / hubert are out of scope
+    cfg.frame_shift = 0.01 if cfg.feature_extractor == "fbank" else 0.02
+
+    cfg.supported_models = ["PyanNet", "PyanNet2"]
+    cfg.model_name = "PyanNet" if cfg.feature_extractor == "sincnet" else "PyanNet2"
+
+    cfg.model_dict = ConfigDict()
+    if cfg.feature_extractor == "sincnet":
+        cfg.model_dict.encoding_dim = 60
+    elif cfg.feature_extractor == "fbank":
+        cfg.model_dict.encoding_dim = 80
+    else:
+        cfg.model_dict.encoding_dim = 768
+
+    cfg.max_duration = 400      # seconds of audio per batch, as the reference's sampler
+
+    cfg.experiments_dir = os.environ.get("UVAD_EXPERIMENTS_DIR", "experiments")
+    cfg.load_checkpoint = False
+    cfg.checkpoint_path = ""
+    cfg.weights_seed = 1234     # used when load_checkpoint is False (no checkpoint ships with the reference)
+    cfg.weights_scale = 4.0
+
+    cfg.predict_output_dir = os.environ.get("UVAD_PREDICT_DIR", "")   # "" = do not write files
+    cfg.window_type = "povey"   # lhotse default; BASELINE cfg 2 uses "hamming"
+
+    # manifest-free input (BASELINE cfg 1: one 30 s 16 kHz utterance)
+    cfg.input = ConfigDict()
+    cfg.input.kind = "synthetic"      # "synthetic" | "wav"
+    cfg.input.paths = []              # wav files (16 kHz mono int16) when kind == "wav"
+    cfg.input.num_utterances = 1
+    cfg.input.seconds = 30.0
+    cfg.input.seed = 1000
+    return cfg

@@ -1,0 +1,111 @@
+// head.hip -- per-frame tail of the classifier and the post-processing next to it.
+//   classifier : logit = z . w + b ; prob = sigmoid(logit)
+//                (reference: self.activation(self.classifier(outputs)),
+//                 src/models/segmentation/PyanNet2.py:187)
+//   untile     : tile-major activation rows -> canonical [B][T][W] (parity taps)
+//   median     : threshold 0.5 + odd binary median, zero padded edges
+//                (reference: median_filter, src/utils/helper.py:66-97, i.e. scipy.signal.medfilt)
+// All three are HBM-bound streaming kernels: 16-byte loads, wave-shuffle reductions, no LDS.
+#include "uvad_internal.h"
+
+namespace uvad {
+
+namespace {
+
+// 16 lanes per row: each lane owns K/16 (<= 16 per pass) elements, 4 rows per wave.
+__global__ __launch_bounds__(256) void classifier_kernel(ClsArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 15, rsel = lane >> 4;
+    const long long rows = (long long)a.tiles * a.T * SEQ_TILE;
+    const long long m = ((long long)blockIdx.x * 4 + wave) * 4 + rsel;
+    float acc = 0.f;
+    if (m < rows) {
+        const float *z = a.Z + (size_t)m * a.ldz;
+        for (int k = sub * 4; k < a.K; k += 64) {
+            if (k + 3 < a.K) {
+                const float4 v = *reinterpret_cast<const float4 *>(z + k);
+                const float4 w = *reinterpret_cast<const float4 *>(a.w + k);
+                acc = __builtin_fmaf(v.x, w.x, acc);
+                acc = __builtin_fmaf(v.y, w.y, acc);
+                acc = __builtin_fmaf(v.z, w.z, acc);
+                acc = __builtin_fmaf(v.w, w.w, acc);
+            } else {
+                for (int e = k; e < a.K; ++e) acc = __builtin_fmaf(z[e], a.w[e], acc);
+            }
+        }
+    }
+    // reduce over the 16 lanes of the row (xor butterflies stay inside the 16-lane group)
+    acc += __shfl_xor(acc, 8);
+    acc += __shfl_xor(acc, 4);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 1);
+    if (sub == 0 && m < rows) {
+        const long long per_tile = (long long)a.T * SEQ_TILE;
+        const int tile = (int)(m / per_tile);
+        const int rem = (int)(m - (long long)tile * per_tile);
+        const int t = rem / SEQ_TILE, j = rem - t * SEQ_TILE;
+        const int b = tile * SEQ_TILE + j;
+        if (b < a.B) {
+            const float logit = acc + a.b[0];
+            const size_t o = (size_t)b * a.T + t;
+            if (a.logits) a.logits[o] = logit;
+            if (a.probs) a.probs[o] = 1.0f / (1.0f + __expf(-logit));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void untile_kernel(const float *src, int ld, int W, float *dst, int tiles, int T, int B) {
+    const long long n4 = (long long)B * T * (W / 4);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % (W / 4));
+        const long long bt = i / (W / 4);
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const int tile = b / SEQ_TILE, j = b - tile * SEQ_TILE;
+        const size_t m = ((size_t)tile * T + t) * SEQ_TILE + j;
+        reinterpret_cast<float4 *>(dst)[i] = *reinterpret_cast<const float4 *>(src + m * ld + q * 4);
+    }
+}
+
+// One thread per output frame; the window count is re-summed (kernel <= 49 taps of L1/L2-resident
+// data: 0.2 kB per thread), which keeps the kernel branch-free and exactly scipy's zero padding.
+__global__ __launch_bounds__(256) void median_kernel(const float *probs, int B, int T, int half, uint8_t *labels) {
+    const long long n = (long long)B * T;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = (int)(i % T);
+    const float *p = probs + (i - t);
+    int ones = 0;
+    for (int d = -half; d <= half; ++d) {
+        const int u = t + d;
+        if (u >= 0 && u < T) ones += !(p[u] < 0.5f);
+    }
+    labels[i] = ones > half ? 1 : 0;
+}
+
+}  // namespace
+
+hipError_t launch_classifier(const ClsArgs &a, hipStream_t s) {
+    const long long rows = (long long)a.tiles * a.T * SEQ_TILE;
+    if (rows <= 0) return hipSuccess;
+    const int grid = (int)((rows + 15) / 16);
+    hipLaunchKernelGGL(classifier_kernel, dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_untile(const float *src, int ld, int W, float *dst, int tiles, int T, int B, hipStream_t s) {
+    const long long n4 = (long long)B * T * (W / 4);
+    if (n4 <= 0) return hipSuccess;
+    long long g = (n4 + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(untile_kernel, dim3((int)g), dim3(256), 0, s, src, ld, W, dst, tiles, T, B);
+    return hipGetLastError();
+}
+
+hipError_t launch_median(const float *probs, int B, int T, int kernel, uint8_t *labels, hipStream_t s) {
+    const long long n = (long long)B * T;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(median_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, s, probs, B, T, kernel / 2, labels);
+    return hipGetLastError();
+}
+
+}  // namespace uvad

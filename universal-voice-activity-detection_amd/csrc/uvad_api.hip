@@ -1,0 +1,477 @@
+// uvad_api.hip -- C ABI of libuvad.so (see include/uvad.h): context, weight repacking into
+// kernel layouts, workspace carving and the launch sequence of the hot path.  Host code only;
+// every compute call enqueues kernels on the caller's stream and returns (no allocation, no
+// synchronisation), so the whole sequence can be captured into a hipGraph by the caller.
+#include "../../include/uvad.h"
+#include "uvad_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace uvad;
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+struct LayerDev {
+    float *w_ih = nullptr;   // [dirs*4H (permuted: dir, unit, gate)][in]
+    float *bias = nullptr;   // [dirs*4H] b_ih + b_hh, same permutation
+    float *w_hh = nullptr;   // [dirs][packed register image]
+    int in = 0;
+};
+
+struct uvad_ctx {
+    int device = 0;
+    bool has_fb = false, has_model = false, finalized = false, tables_set = false;
+    uvad_fbank_cfg fb{};
+    uvad_model_cfg mc{};
+    std::string err;
+    std::map<std::string, HostTensor> host_w;
+    // device
+    float *d_window = nullptr, *d_mel_w = nullptr, *d_tw512 = nullptr;
+    int *d_mel_start = nullptr, *d_mel_len = nullptr;
+    int mel_stride = 0;
+    std::vector<LayerDev> layers;
+    std::vector<float *> lin_w, lin_b;
+    float *cls_w = nullptr, *cls_b = nullptr;
+    std::vector<void *> allocs;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    float proj_ms = 0.f, rec_ms = 0.f;
+    std::vector<hipEvent_t> layer_ev;
+};
+
+namespace {
+
+int fail(uvad_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    return code;
+}
+int hip_fail(uvad_ctx *c, hipError_t e, const char *what) {
+    return fail(c, UVAD_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(c, call)                                        \
+    do {                                                       \
+        hipError_t e_ = (call);                                \
+        if (e_ != hipSuccess) return hip_fail((c), e_, #call); \
+    } while (0)
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+template <typename T>
+int dev_upload(uvad_ctx *c, const T *host, size_t n, T **out) {
+    void *p = nullptr;
+    HIPCHK(c, hipMalloc(&p, n * sizeof(T) ? n * sizeof(T) : sizeof(T)));
+    c->allocs.push_back(p);
+    if (n) HIPCHK(c, hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<T *>(p);
+    return UVAD_OK;
+}
+
+// Workspace carving for B sequences of T frames (all offsets in bytes, 256-B aligned).
+struct WsLayout {
+    int tiles = 0, D = 0, Wd = 0;
+    size_t M = 0;
+    size_t off_G = 0, off_Y[2] = {0, 0}, off_Z[2] = {0, 0}, off_feats = 0, total = 0;
+};
+WsLayout carve(const uvad_ctx *c, int B, int64_t T) {
+    WsLayout w;
+    const uvad_model_cfg &m = c->mc;
+    w.tiles = (B + SEQ_TILE - 1) / SEQ_TILE;
+    w.D = m.bidirectional ? 2 : 1;
+    w.Wd = m.hidden * w.D;
+    w.M = (size_t)w.tiles * SEQ_TILE * (size_t)T;
+    size_t o = 0;
+    w.off_G = o; o += align_up(w.M * 4 * m.hidden * w.D * sizeof(float));
+    for (int i = 0; i < 2; ++i) { w.off_Y[i] = o; o += align_up(w.M * w.Wd * sizeof(float)); }
+    for (int i = 0; i < 2; ++i) { w.off_Z[i] = o; o += align_up(w.M * (size_t)(m.lin_layers > 0 ? m.lin_hidden : 0) * sizeof(float)); }
+    w.off_feats = o; o += align_up((size_t)B * T * (c->has_fb ? (size_t)c->fb.n_mels : (size_t)m.in_dim) * sizeof(float));
+    w.total = o;
+    return w;
+}
+
+std::string strip_prefix(const char *key) {
+    std::string k(key);
+    if (k.rfind("model.", 0) == 0) k = k.substr(6);
+    // ModuleList-of-LSTMs variant (monolithic=False, PyanNet2.py:103-118): lstm.{k}.weight_ih_l0[_reverse]
+    if (k.rfind("lstm.", 0) == 0 && k.size() > 5 && isdigit((unsigned char)k[5])) {
+        size_t dot = k.find('.', 5);
+        if (dot != std::string::npos) {
+            const std::string layer = k.substr(5, dot - 5);
+            std::string rest = k.substr(dot + 1);
+            const size_t l0 = rest.find("_l0");
+            if (l0 != std::string::npos) {
+                rest.replace(l0, 3, "_l" + layer);
+                k = "lstm." + rest;
+            }
+        }
+    }
+    return k;
+}
+
+bool expect_shape(const HostTensor &t, std::initializer_list<int64_t> want) {
+    if (t.shape.size() != want.size()) return false;
+    size_t i = 0;
+    for (int64_t w : want)
+        if (t.shape[i++] != w) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uvad_abi_version(void) { return UVAD_ABI_VERSION; }
+
+int uvad_create(int device, const uvad_fbank_cfg *fb, const uvad_model_cfg *model, uvad_ctx **out) {
+    if (!out) return UVAD_E_ARG;
+    *out = nullptr;
+    uvad_ctx *c = new uvad_ctx();
+    *out = c;  // returned even on failure so uvad_last_error() can be read; caller destroys it
+    c->device = device;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(c, UVAD_E_HIP, std::string("no HIP device available (libuvad has no CPU fallback): ") +
+                                       (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device < 0 || device >= ndev) return fail(c, UVAD_E_ARG, "device index out of range");
+    HIPCHK(c, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(c, UVAD_E_HIP, std::string("libuvad is built for gfx950 only; device is ") + prop.gcnArchName);
+    if (fb) {
+        c->fb = *fb;
+        c->has_fb = true;
+        if (fb->n_fft != 512) return fail(c, UVAD_E_UNSUPPORTED, "only n_fft = 512 is implemented");
+        if (fb->frame_len < 2 || fb->frame_len > 512 || fb->frame_shift < 1 || fb->n_mels < 1 || fb->n_mels > 1024)
+            return fail(c, UVAD_E_ARG, "bad fbank configuration");
+        // forward-FFT twiddles (cos, -sin)(2 pi j / 512), computed in double
+        std::vector<float> tw(2 * 512);
+        for (int j = 0; j < 512; ++j) {
+            const double a = 2.0 * M_PI * j / 512.0;
+            tw[2 * j] = (float)std::cos(a);
+            tw[2 * j + 1] = (float)(-std::sin(a));
+        }
+        int r = dev_upload(c, tw.data(), tw.size(), &c->d_tw512);
+        if (r) return r;
+    }
+    if (model) {
+        c->mc = *model;
+        c->has_model = true;
+        if (model->hidden != 128 && model->hidden != 64)
+            return fail(c, UVAD_E_UNSUPPORTED, "lstm hidden_size must be 128 or 64 (register-resident W_hh kernel)");
+        if (model->in_dim < 4 || model->in_dim % 4 != 0)
+            return fail(c, UVAD_E_UNSUPPORTED, "encoding_dim must be a positive multiple of 4");
+        if (model->num_layers < 1 || model->lin_layers < 0 || (model->lin_layers > 0 && (model->lin_hidden < 4 || model->lin_hidden % 4)))
+            return fail(c, UVAD_E_ARG, "bad model configuration");
+    }
+    for (auto &ev : c->ev) HIPCHK(c, hipEventCreate(&ev));
+    return UVAD_OK;
+}
+
+int uvad_set_tables(uvad_ctx *c, const float *window, const float *mel) {
+    if (!c || !window || !mel) return UVAD_E_ARG;
+    if (!c->has_fb) return fail(c, UVAD_E_STATE, "context was created without a fbank configuration");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int nb = c->fb.n_fft / 2 + 1, F = c->fb.n_mels;
+    std::vector<int> st(F), ln(F);
+    int maxlen = 1;
+    for (int m = 0; m < F; ++m) {
+        int lo = nb, hi = -1;
+        for (int k = 0; k < nb; ++k)
+            if (mel[(size_t)m * nb + k] != 0.0f) { if (k < lo) lo = k; hi = k; }
+        st[m] = hi < 0 ? 0 : lo;
+        ln[m] = hi < 0 ? 0 : hi - lo + 1;
+        if (ln[m] > maxlen) maxlen = ln[m];
+    }
+    c->mel_stride = maxlen;
+    std::vector<float> w((size_t)F * maxlen, 0.0f);
+    for (int m = 0; m < F; ++m)
+        for (int i = 0; i < ln[m]; ++i) w[(size_t)m * maxlen + i] = mel[(size_t)m * nb + st[m] + i];
+    int r;
+    if ((r = dev_upload(c, window, (size_t)c->fb.frame_len, &c->d_window))) return r;
+    if ((r = dev_upload(c, st.data(), st.size(), &c->d_mel_start))) return r;
+    if ((r = dev_upload(c, ln.data(), ln.size(), &c->d_mel_len))) return r;
+    if ((r = dev_upload(c, w.data(), w.size(), &c->d_mel_w))) return r;
+    c->tables_set = true;
+    return UVAD_OK;
+}
+
+int uvad_set_weight(uvad_ctx *c, const char *torch_key, const float *host, const int64_t *shape, int ndim) {
+    if (!c || !torch_key || !host || !shape || ndim < 1 || ndim > 2) return UVAD_E_ARG;
+    if (!c->has_model) return fail(c, UVAD_E_STATE, "context was created without a model configuration");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] <= 0) return fail(c, UVAD_E_ARG, "non-positive dimension");
+        t.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    t.data.assign(host, host + n);
+    c->host_w[strip_prefix(torch_key)] = std::move(t);
+    c->finalized = false;
+    return UVAD_OK;
+}
+
+int uvad_finalize(uvad_ctx *c) {
+    if (!c) return UVAD_E_ARG;
+    if (!c->has_model) return fail(c, UVAD_E_STATE, "no model configuration");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uvad_model_cfg &m = c->mc;
+    const int H = m.hidden, D = m.bidirectional ? 2 : 1;
+    auto get = [&](const std::string &k) -> const HostTensor * {
+        auto it = c->host_w.find(k);
+        return it == c->host_w.end() ? nullptr : &it->second;
+    };
+    c->layers.assign(m.num_layers, LayerDev());
+    for (int k = 0; k < m.num_layers; ++k) {
+        const int in = k == 0 ? m.in_dim : H * D;
+        std::vector<float> wp((size_t)D * 4 * H * in), bp((size_t)D * 4 * H), hh((size_t)D * whh_packed_elems(H));
+        for (int d = 0; d < D; ++d) {
+            const std::string suf = "_l" + std::to_string(k) + (d ? "_reverse" : "");
+            const HostTensor *wih = get("lstm.weight_ih" + suf), *whh = get("lstm.weight_hh" + suf);
+            const HostTensor *bih = get("lstm.bias_ih" + suf), *bhh = get("lstm.bias_hh" + suf);
+            if (!wih || !whh || !bih || !bhh) return fail(c, UVAD_E_STATE, "missing LSTM tensor for suffix " + suf);
+            if (!expect_shape(*wih, {4 * H, in}) || !expect_shape(*whh, {4 * H, H}) ||
+                !expect_shape(*bih, {4 * H}) || !expect_shape(*bhh, {4 * H}))
+                return fail(c, UVAD_E_ARG, "LSTM tensor shape mismatch for suffix " + suf);
+            // torch rows are gate-major (i,f,g,o blocks of H); kernels want (unit, gate) interleaved
+            for (int u = 0; u < H; ++u)
+                for (int g = 0; g < 4; ++g) {
+                    const size_t dst = (size_t)d * 4 * H + (size_t)u * 4 + g, src = (size_t)g * H + u;
+                    std::memcpy(&wp[dst * in], &wih->data[src * in], sizeof(float) * in);
+                    bp[dst] = bih->data[src] + bhh->data[src];
+                }
+            pack_whh(whh->data.data(), H, &hh[(size_t)d * whh_packed_elems(H)]);
+        }
+        LayerDev &L = c->layers[k];
+        L.in = in;
+        int r;
+        if ((r = dev_upload(c, wp.data(), wp.size(), &L.w_ih))) return r;
+        if ((r = dev_upload(c, bp.data(), bp.size(), &L.bias))) return r;
+        if ((r = dev_upload(c, hh.data(), hh.size(), &L.w_hh))) return r;
+    }
+    c->lin_w.assign(m.lin_layers, nullptr);
+    c->lin_b.assign(m.lin_layers, nullptr);
+    int prev = H * D;
+    for (int j = 0; j < m.lin_layers; ++j) {
+        const HostTensor *w = get("linear." + std::to_string(j) + ".weight"), *b = get("linear." + std::to_string(j) + ".bias");
+        if (!w || !b) return fail(c, UVAD_E_STATE, "missing linear." + std::to_string(j));
+        if (!expect_shape(*w, {m.lin_hidden, prev}) || !expect_shape(*b, {m.lin_hidden}))
+            return fail(c, UVAD_E_ARG, "linear." + std::to_string(j) + " shape mismatch");
+        int r;
+        if ((r = dev_upload(c, w->data.data(), w->data.size(), &c->lin_w[j]))) return r;
+        if ((r = dev_upload(c, b->data.data(), b->data.size(), &c->lin_b[j]))) return r;
+        prev = m.lin_hidden;
+    }
+    const HostTensor *cw = get("classifier.weight"), *cb = get("classifier.bias");
+    if (!cw || !cb) return fail(c, UVAD_E_STATE, "missing classifier tensors");
+    if (!expect_shape(*cw, {1, prev}) || !expect_shape(*cb, {1})) return fail(c, UVAD_E_ARG, "classifier shape mismatch");
+    int r;
+    if ((r = dev_upload(c, cw->data.data(), cw->data.size(), &c->cls_w))) return r;
+    if ((r = dev_upload(c, cb->data.data(), cb->data.size(), &c->cls_b))) return r;
+    c->layer_ev.resize((size_t)2 * m.num_layers + 2);
+    for (auto &ev : c->layer_ev) HIPCHK(c, hipEventCreate(&ev));
+    c->finalized = true;
+    return UVAD_OK;
+}
+
+int64_t uvad_num_frames(const uvad_ctx *c, int64_t S) {
+    if (!c || !c->has_fb || S < 0) return -1;
+    if (c->fb.snip_edges) return S < c->fb.frame_len ? 0 : 1 + (S - c->fb.frame_len) / c->fb.frame_shift;
+    return (S + c->fb.frame_shift / 2) / c->fb.frame_shift;
+}
+
+size_t uvad_workspace_bytes(const uvad_ctx *c, int B, int64_t T) {
+    if (!c || !c->has_model || B <= 0 || T <= 0) return 0;
+    return carve(c, B, T).total;
+}
+
+static int fbank_impl(uvad_ctx *c, const void *d_pcm, int is_i16, int B, int64_t S, float *d_feats, void *stream) {
+    if (!c || !d_pcm || !d_feats || B <= 0 || S <= 0) return fail(c, UVAD_E_ARG, "uvad_fbank: bad argument");
+    if (!c->has_fb || !c->tables_set) return fail(c, UVAD_E_STATE, "uvad_fbank: uvad_set_tables has not been called");
+    const int64_t T = uvad_num_frames(c, S);
+    if (T <= 0) return fail(c, UVAD_E_ARG, "uvad_fbank: input shorter than one frame");
+    if (B > 65535) return fail(c, UVAD_E_UNSUPPORTED, "uvad_fbank: B > 65535 (grid.y); split the batch");
+    FbankArgs a{};
+    a.pcm = d_pcm; a.pcm_is_i16 = is_i16; a.B = B; a.S = S; a.T = T;
+    a.frame_len = c->fb.frame_len; a.frame_shift = c->fb.frame_shift; a.n_mels = c->fb.n_mels;
+    a.preemph = c->fb.preemph; a.log_floor = c->fb.log_floor; a.remove_dc = c->fb.remove_dc; a.snip_edges = c->fb.snip_edges;
+    a.feats = d_feats;
+    a.tab.window = c->d_window; a.tab.mel_start = c->d_mel_start; a.tab.mel_len = c->d_mel_len;
+    a.tab.mel_w = c->d_mel_w; a.tab.mel_stride = c->mel_stride; a.tab.tw512 = c->d_tw512;
+    HIPCHK(c, launch_fbank(a, (hipStream_t)stream));
+    return UVAD_OK;
+}
+
+int uvad_fbank(uvad_ctx *c, const float *d_pcm, int B, int64_t S, float *d_feats, void *stream) {
+    return fbank_impl(c, d_pcm, 0, B, S, d_feats, stream);
+}
+int uvad_fbank_i16(uvad_ctx *c, const int16_t *d_pcm, int B, int64_t S, float *d_feats, void *stream) {
+    return fbank_impl(c, d_pcm, 1, B, S, d_feats, stream);
+}
+
+static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float *d_logits, float *d_probs,
+                         void *ws, size_t ws_bytes, hipStream_t s, bool record_start) {
+    const uvad_model_cfg &m = c->mc;
+    const WsLayout w = carve(c, B, T);
+    if (ws_bytes < w.total) return fail(c, UVAD_E_WORKSPACE, "workspace too small: need " + std::to_string(w.total) + " bytes");
+    if (w.M > (size_t)0x7fffffff) return fail(c, UVAD_E_UNSUPPORTED, "B*T exceeds 2^31 rows; split the batch");
+    char *base = reinterpret_cast<char *>(ws);
+    float *G = reinterpret_cast<float *>(base + w.off_G);
+    float *Y[2] = {reinterpret_cast<float *>(base + w.off_Y[0]), reinterpret_cast<float *>(base + w.off_Y[1])};
+    float *Z[2] = {reinterpret_cast<float *>(base + w.off_Z[0]), reinterpret_cast<float *>(base + w.off_Z[1])};
+    const int H = m.hidden, D = w.D, N4 = 4 * H * D;
+    if (c->timing && record_start) HIPCHK(c, hipEventRecord(c->ev[0], s));
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
+    for (int k = 0; k < m.num_layers; ++k) {
+        const LayerDev &L = c->layers[k];
+        GemmArgs g{};
+        g.W = L.w_ih; g.bias = L.bias; g.C = G; g.M = (int)w.M; g.N = N4; g.K = L.in; g.ldc = N4;
+        g.B = B; g.T = T; g.act = 0; g.leaky_slope = 0.f;
+        if (k == 0) { g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1; }
+        else { g.A = Y[(k - 1) & 1]; g.lda = w.Wd; g.a_mode = 0; }
+        if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k], s));
+        HIPCHK(c, launch_gemm(g, s));
+        if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k + 1], s));
+        LstmArgs r{};
+        r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.Y = Y[k & 1]; r.ldy = w.Wd;
+        r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D;
+        HIPCHK(c, launch_lstm(r, s));
+    }
+    if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * m.num_layers], s));
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
+    const float *cur = Y[(m.num_layers - 1) & 1];
+    int curw = w.Wd;
+    for (int j = 0; j < m.lin_layers; ++j) {
+        GemmArgs g{};
+        g.A = cur; g.lda = curw; g.a_mode = 0; g.W = c->lin_w[j]; g.bias = c->lin_b[j]; g.C = Z[j & 1];
+        g.M = (int)w.M; g.N = m.lin_hidden; g.K = curw; g.ldc = m.lin_hidden; g.B = B; g.T = T;
+        g.act = 1; g.leaky_slope = m.leaky_slope;
+        HIPCHK(c, launch_gemm(g, s));
+        cur = Z[j & 1];
+        curw = m.lin_hidden;
+    }
+    ClsArgs q{};
+    q.Z = cur; q.ldz = curw; q.K = curw; q.w = c->cls_w; q.b = c->cls_b; q.logits = d_logits; q.probs = d_probs;
+    q.tiles = w.tiles; q.T = T; q.B = B;
+    HIPCHK(c, launch_classifier(q, s));
+    if (c->timing) {
+        HIPCHK(c, hipEventRecord(c->ev[3], s));
+        c->ev_valid = true;
+    }
+    return UVAD_OK;
+}
+
+int uvad_classify(uvad_ctx *c, const float *d_feats, int B, int T, float *d_logits, float *d_probs,
+                  void *ws, size_t ws_bytes, void *stream) {
+    if (!c) return UVAD_E_ARG;
+    if (!d_feats || B <= 0 || T <= 0 || !ws) return fail(c, UVAD_E_ARG, "uvad_classify: bad argument");
+    if (!c->finalized) return fail(c, UVAD_E_STATE, "uvad_classify: uvad_finalize has not been called");
+    return classify_impl(c, d_feats, B, T, d_logits, d_probs, ws, ws_bytes, (hipStream_t)stream, true);
+}
+
+int uvad_forward(uvad_ctx *c, const float *d_pcm, int B, int64_t S, float *d_logits, float *d_probs,
+                 void *ws, size_t ws_bytes, void *stream) {
+    if (!c) return UVAD_E_ARG;
+    if (!d_pcm || B <= 0 || S <= 0 || !ws) return fail(c, UVAD_E_ARG, "uvad_forward: bad argument");
+    if (!c->finalized) return fail(c, UVAD_E_STATE, "uvad_forward: uvad_finalize has not been called");
+    if (!c->has_fb || !c->tables_set) return fail(c, UVAD_E_STATE, "uvad_forward: uvad_set_tables has not been called");
+    if (c->fb.n_mels != c->mc.in_dim) return fail(c, UVAD_E_ARG, "uvad_forward: n_mels != encoding_dim");
+    const int64_t T = uvad_num_frames(c, S);
+    if (T <= 0 || T > 0x7fffffff) return fail(c, UVAD_E_ARG, "uvad_forward: bad frame count");
+    const WsLayout w = carve(c, B, T);
+    if (ws_bytes < w.total) return fail(c, UVAD_E_WORKSPACE, "workspace too small: need " + std::to_string(w.total) + " bytes");
+    float *feats = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + w.off_feats);
+    hipStream_t s = (hipStream_t)stream;
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
+    int r = fbank_impl(c, d_pcm, 0, B, S, feats, stream);
+    if (r) return r;
+    return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, ws_bytes, s, false);
+}
+
+int uvad_get_taps(uvad_ctx *c, int B, int T, float *d_lstm_out, float *d_lin_out, const void *ws, void *stream) {
+    if (!c || !ws || B <= 0 || T <= 0) return UVAD_E_ARG;
+    if (!c->finalized) return fail(c, UVAD_E_STATE, "not finalized");
+    const uvad_model_cfg &m = c->mc;
+    const WsLayout w = carve(c, B, T);
+    const char *base = reinterpret_cast<const char *>(ws);
+    if (d_lstm_out) {
+        const float *y = reinterpret_cast<const float *>(base + w.off_Y[(m.num_layers - 1) & 1]);
+        HIPCHK(c, launch_untile(y, w.Wd, w.Wd, d_lstm_out, w.tiles, T, B, (hipStream_t)stream));
+    }
+    if (d_lin_out) {
+        if (m.lin_layers <= 0) return fail(c, UVAD_E_ARG, "model has no feed-forward layers");
+        const float *z = reinterpret_cast<const float *>(base + w.off_Z[(m.lin_layers - 1) & 1]);
+        HIPCHK(c, launch_untile(z, m.lin_hidden, m.lin_hidden, d_lin_out, w.tiles, T, B, (hipStream_t)stream));
+    }
+    return UVAD_OK;
+}
+
+size_t uvad_stream_state_bytes(const uvad_ctx *c, int B) {
+    (void)c; (void)B;
+    return 0;
+}
+
+int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, void *d_state, float *d_logits,
+                     void *ws, size_t ws_bytes, void *stream) {
+    (void)d_pcm_chunk; (void)B; (void)chunk; (void)d_state; (void)d_logits; (void)ws; (void)ws_bytes; (void)stream;
+    return fail(c, UVAD_E_UNSUPPORTED, "uvad_stream_step: streaming is not implemented in this build");
+}
+
+int uvad_median_filter(uvad_ctx *c, const float *d_probs, int B, int T, int kernel, uint8_t *d_labels, void *stream) {
+    if (!c || !d_probs || !d_labels || B <= 0 || T <= 0) return UVAD_E_ARG;
+    if (kernel < 1 || kernel % 2 == 0) return fail(c, UVAD_E_ARG, "median kernel must be odd");
+    HIPCHK(c, launch_median(d_probs, B, T, kernel, d_labels, (hipStream_t)stream));
+    return UVAD_OK;
+}
+
+int uvad_set_timing(uvad_ctx *c, int enabled) {
+    if (!c) return UVAD_E_ARG;
+    c->timing = enabled != 0;
+    c->ev_valid = false;
+    return UVAD_OK;
+}
+
+int uvad_get_timing(uvad_ctx *c, float ms[5]) {
+    if (!c || !ms) return UVAD_E_ARG;
+    if (!c->ev_valid) return fail(c, UVAD_E_STATE, "no timed call recorded");
+    HIPCHK(c, hipEventSynchronize(c->ev[3]));
+    const int L = c->mc.num_layers;
+    float fb = 0.f, proj = 0.f, rec = 0.f, head = 0.f, total = 0.f, t = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&fb, c->ev[0], c->ev[1]));
+    for (int k = 0; k < L; ++k) {
+        HIPCHK(c, hipEventElapsedTime(&t, c->layer_ev[2 * k], c->layer_ev[2 * k + 1]));
+        proj += t;
+        HIPCHK(c, hipEventElapsedTime(&t, c->layer_ev[2 * k + 1], c->layer_ev[2 * k + 2]));
+        rec += t;
+    }
+    HIPCHK(c, hipEventElapsedTime(&head, c->ev[2], c->ev[3]));
+    HIPCHK(c, hipEventElapsedTime(&total, c->ev[0], c->ev[3]));
+    ms[0] = fb; ms[1] = proj; ms[2] = rec; ms[3] = head; ms[4] = total;
+    return UVAD_OK;
+}
+
+const char *uvad_last_error(const uvad_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+void uvad_destroy(uvad_ctx *c) {
+    if (!c) return;
+    if (!c->allocs.empty() || c->ev[0]) (void)hipSetDevice(c->device);
+    for (void *p : c->allocs) (void)hipFree(p);
+    for (auto &ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->layer_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    delete c;
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+// Internal launcher declarations shared by the translation units of libuvad.so.
+// Everything here is gfx950-only HIP; no torch types, no CPU fallbacks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace uvad {
+
+// Sequences are processed in tiles of SEQ_TILE batch entries: activation rows are ordered
+//   m = (tile * T + t) * SEQ_TILE + j,   b = tile * SEQ_TILE + j
+// so that the SEQ_TILE rows one recurrent workgroup needs at step t are adjacent in HBM.
+constexpr int SEQ_TILE = 4;
+
+// ---- gemm.hip -----------------------------------------------------------------------------
+// C[M][ldc] (cols [0,N)) = act( A[M][K] * W[N][K]^T + bias[N] ), exact f32 on v_mfma_f32_32x32x2_f32.
+struct GemmArgs {
+    const float *A;      // activations
+    const float *W;      // [N][K] row-major (torch Linear / LSTM weight layout, rows possibly permuted)
+    const float *bias;   // [N] or nullptr
+    float *C;
+    int M, N, K;
+    int lda, ldc;
+    // a_mode 0: row m of A is A + m*lda.
+    // a_mode 1: A is canonical [B][T][K]; row m = (tile*T + t)*SEQ_TILE + j reads sequence
+    //           b = tile*SEQ_TILE + j at frame t (zeros when b >= B).
+    int a_mode, B, T;
+    float leaky_slope;   // act: v >= 0 ? v : slope*v when act == 1
+    int act;
+};
+hipError_t launch_gemm(const GemmArgs &a, hipStream_t s);
+
+// ---- lstm.hip -----------------------------------------------------------------------------
+// One layer, all directions: grid (tiles, dirs).  G holds x_t*W_ih^T + b_ih + b_hh with column
+// dir*4H + u*4 + gate; Y gets h_t at column dir*H + u.  Rows as above.
+struct LstmArgs {
+    const float *G; int ldg;
+    const float *Whh_packed;     // per dir: register image, see pack_whh()
+    float *Y; int ldy;
+    int tiles, T, H, dirs;
+    // optional carried state (streaming): [dirs][tiles*SEQ_TILE][H], nullptr = zeros / discard
+    const float *h0, *c0; float *hN, *cN;
+};
+hipError_t launch_lstm(const LstmArgs &a, hipStream_t s);
+// elements of the packed W_hh image for one direction
+size_t whh_packed_elems(int H);
+// host-side packer: torch w_hh [4H][H] (rows i,f,g,o) -> register image
+void pack_whh(const float *w_hh, int H, float *out);
+
+// ---- head.hip -----------------------------------------------------------------------------
+// logit = Z[m][:K] . w + b ; prob = sigmoid(logit); written at canonical [b][t] (b < B only).
+struct ClsArgs {
+    const float *Z; int ldz, K;
+    const float *w, *b;
+    float *logits, *probs;   // either may be nullptr
+    int tiles, T, B;
+};
+hipError_t launch_classifier(const ClsArgs &a, hipStream_t s);
+// rows (tile-major) -> canonical [B][T][W] copy, for the parity taps
+hipError_t launch_untile(const float *src, int lds_, int W, float *dst, int tiles, int T, int B, hipStream_t s);
+// threshold 0.5 + binary median
+hipError_t launch_median(const float *probs, int B, int T, int kernel, uint8_t *labels, hipStream_t s);
+
+// ---- fbank.hip ----------------------------------------------------------------------------
+struct FbankTables {            // device pointers owned by the ctx
+    const float *window;        // [frame_len]
+    const int *mel_start;       // [n_mels] first bin with non-zero weight
+    const int *mel_len;         // [n_mels] number of bins
+    const float *mel_w;         // [n_mels][mel_stride] weights (zero padded)
+    int mel_stride;             // max band length rounded up
+    const float *tw512;         // [512][2] (cos, -sin)(2*pi*j/512): forward FFT twiddles
+};
+struct FbankArgs {
+    const void *pcm; int pcm_is_i16;
+    int B; int64_t S; int64_t T;
+    int frame_len, frame_shift, n_mels;
+    float preemph, log_floor; int remove_dc, snip_edges;
+    float *feats;               // [B][T][n_mels]
+    FbankTables tab;
+};
+hipError_t launch_fbank(const FbankArgs &a, hipStream_t s);
+size_t fbank_lds_bytes(const FbankArgs &a);
+
+}  // namespace uvad

@@ -1,0 +1,71 @@
+"""Multi-GPU: the path shards by utterance with no exchange step.  Every
+utterance is an independent sequence and the weights (5.8 MB) are replicated, so ranks need no
+data-path collective: rank r owns utterances {i : i mod world == r} (``shard_indices``), generates
+or loads exactly those, and runs the single-GPU path.  The only communication is the optional
+gather of the per-frame outputs to rank 0 (``gather_rows``; RCCL when the tensors are on the GPU,
+gloo in the CPU tests) -- tiny: B/world * T * 4 bytes per rank."""
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def dist_env():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init(backend: Optional[str] = None):
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    rank, local_rank, world = dist_env()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_indices(n: int, rank: int, world: int) -> List[int]:
+    """Utterance i -> rank i mod world.  Stable under any world size, so utterance i
+    always gets the same synthetic signal and the same result."""
+    return list(range(rank, n, world))
+
+
+def shard_count(n: int, rank: int, world: int) -> int:
+    return (n - rank + world - 1) // world if n > rank else 0
+
+
+def gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int) -> Optional[torch.Tensor]:
+    """Inverse of ``shard_indices``: rows held by each rank -> full (n_total, ...) tensor on rank 0
+    (None elsewhere).  Shards may differ by one row, so they are padded to the largest."""
+    if world == 1:
+        return local
+    per = (n_total + world - 1) // world
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, bufs, dst=0)
+    if rank != 0:
+        return None
+    out = torch.empty((n_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        idx = shard_indices(n_total, r, world)
+        out[idx] = bufs[r][: len(idx)]
+    return out
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    if not (dist.is_available() and dist.is_initialized()):
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()

@@ -1,0 +1,190 @@
+"""VadRuntime: owns one ``uvad_ctx`` (device, model) and the device workspace; torch tensors are
+used only as device-memory containers whose ``data_ptr()`` is handed to the C ABI together with
+torch's current HIP stream.  Every method fails loudly if libuvad.so or the GPU is missing."""
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .features import FbankConfig, make_mel_matrix, make_window
+
+
+def _model_cfg(encoding_dim: int, lstm: dict, linear: dict, leaky_slope: float = 0.01) -> _lib.ModelCfg:
+    return _lib.ModelCfg(int(encoding_dim), int(lstm["hidden_size"]), int(lstm["num_layers"]),
+                         int(bool(lstm["bidirectional"])), int(linear.get("hidden_size", 128)),
+                         int(linear.get("num_layers", 0)), float(leaky_slope))
+
+
+class VadRuntime:
+    def __init__(self, device, fbank: Optional[FbankConfig] = None, model: Optional[dict] = None):
+        """model: {"encoding_dim": int, "lstm": {...merged defaults...}, "linear": {...}} or None."""
+        self.lib = _lib.load()
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError(f"VadRuntime needs a GPU device, got {dev}; there is no CPU path")
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible to torch; libuvad has no CPU fallback")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.fbank_cfg = fbank
+        self.model_cfg = model
+        fb_c = mc_c = None
+        if fbank is not None:
+            fb_c = _lib.FbankCfg(fbank.sampling_rate, fbank.frame_len_samples, fbank.frame_shift_samples, fbank.n_fft,
+                                 fbank.num_filters, fbank.preemph_coeff, fbank.low_freq, fbank.high_freq,
+                                 fbank.energy_floor, int(fbank.remove_dc_offset), int(fbank.snip_edges))
+        if model is not None:
+            mc_c = _model_cfg(model["encoding_dim"], model["lstm"], model["linear"], model.get("leaky_slope", 0.01))
+        self._fb_c, self._mc_c = fb_c, mc_c
+        self.ctx = C.c_void_p()
+        code = self.lib.uvad_create(dev.index, C.byref(fb_c) if fb_c else None, C.byref(mc_c) if mc_c else None,
+                                    C.byref(self.ctx))
+        try:
+            _lib.check(self.lib, self.ctx, code)
+        except Exception:
+            self.close()
+            raise
+        if fbank is not None:
+            win = make_window(fbank.window_type, fbank.frame_len_samples)
+            mel = make_mel_matrix(fbank.num_filters, fbank.n_fft, fbank.sampling_rate, fbank.low_freq,
+                                  fbank.high_freq, fbank.norm_filters)
+            self.set_tables(win, mel)
+        self._ws = None
+        self._finalized = False
+
+    # ------------------------------------------------------------------ setup
+    def set_tables(self, window: np.ndarray, mel: np.ndarray):
+        window = np.ascontiguousarray(window, np.float32)
+        mel = np.ascontiguousarray(mel, np.float32)
+        assert window.shape == (self._fb_c.frame_len,), window.shape
+        assert mel.shape == (self._fb_c.n_mels, self._fb_c.n_fft // 2 + 1), mel.shape
+        self._check(self.lib.uvad_set_tables(self.ctx, window.ctypes.data, mel.ctypes.data))
+
+    def load_state_dict(self, sd: Dict[str, "torch.Tensor"]):
+        """torch-keyed tensors (CPU or GPU; a Lightning ``model.`` prefix is accepted)."""
+        for k, v in sd.items():
+            a = np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy() if torch.is_tensor(v) else v, np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            self._check(self.lib.uvad_set_weight(self.ctx, k.encode(), a.ctypes.data, shape, a.ndim))
+        self._check(self.lib.uvad_finalize(self.ctx))
+        self._finalized = True
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, code):
+        _lib.check(self.lib, self.ctx, code)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev_f32(self, t: "torch.Tensor", name: str) -> "torch.Tensor":
+        if not torch.is_tensor(t) or t.device != self.device:
+            raise RuntimeError(f"{name} must be a tensor on {self.device} (got {getattr(t, 'device', type(t))})")
+        if t.dtype != torch.float32:
+            t = t.float()
+        return t.contiguous()
+
+    def num_frames(self, S: int) -> int:
+        return int(self.lib.uvad_num_frames(self.ctx, S))
+
+    def workspace(self, B: int, T: int) -> "torch.Tensor":
+        need = int(self.lib.uvad_workspace_bytes(self.ctx, B, T))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ------------------------------------------------------------------ compute
+    def fbank(self, pcm: "torch.Tensor") -> "torch.Tensor":
+        """pcm (B,S) f32 or int16 on the GPU -> (B,T,n_mels) f32."""
+        with torch.cuda.device(self.device):
+            if pcm.dtype == torch.int16:
+                if pcm.device != self.device:
+                    raise RuntimeError(f"pcm must be on {self.device}")
+                pcm = pcm.contiguous()
+                fn = self.lib.uvad_fbank_i16
+            else:
+                pcm = self._dev_f32(pcm, "pcm")
+                fn = self.lib.uvad_fbank
+            B, S = pcm.shape
+            T = self.num_frames(S)
+            feats = torch.empty((B, T, self._fb_c.n_mels), dtype=torch.float32, device=self.device)
+            self._check(fn(self.ctx, pcm.data_ptr(), B, S, feats.data_ptr(), self._stream()))
+            return feats
+
+    def classify(self, feats: "torch.Tensor", want_logits=True, want_probs=True):
+        """feats (B,T,F) on the GPU -> (logits (B,T) | None, probs (B,T) | None)."""
+        with torch.cuda.device(self.device):
+            feats = self._dev_f32(feats, "feats")
+            B, T, F = feats.shape
+            if F != self._mc_c.in_dim:
+                raise ValueError(f"feature dim {F} != encoding_dim {self._mc_c.in_dim}")
+            ws = self.workspace(B, T)
+            logits = torch.empty((B, T), dtype=torch.float32, device=self.device) if want_logits else None
+            probs = torch.empty((B, T), dtype=torch.float32, device=self.device) if want_probs else None
+            self._check(self.lib.uvad_classify(self.ctx, feats.data_ptr(), B, T,
+                                               logits.data_ptr() if want_logits else None,
+                                               probs.data_ptr() if want_probs else None,
+                                               ws.data_ptr(), ws.numel(), self._stream()))
+            self._last_bt = (B, T)
+            return logits, probs
+
+    def forward(self, pcm: "torch.Tensor", want_logits=True, want_probs=True):
+        """pcm (B,S) f32 on the GPU -> (logits, probs); features never leave the workspace."""
+        with torch.cuda.device(self.device):
+            pcm = self._dev_f32(pcm, "pcm")
+            B, S = pcm.shape
+            T = self.num_frames(S)
+            ws = self.workspace(B, T)
+            logits = torch.empty((B, T), dtype=torch.float32, device=self.device) if want_logits else None
+            probs = torch.empty((B, T), dtype=torch.float32, device=self.device) if want_probs else None
+            self._check(self.lib.uvad_forward(self.ctx, pcm.data_ptr(), B, S,
+                                              logits.data_ptr() if want_logits else None,
+                                              probs.data_ptr() if want_probs else None,
+                                              ws.data_ptr(), ws.numel(), self._stream()))
+            self._last_bt = (B, T)
+            return logits, probs
+
+    def taps(self):
+        """(lstm_out (B,T,H*D), lin_out (B,T,lin_hidden) | None) of the last classify/forward."""
+        with torch.cuda.device(self.device):
+            B, T = self._last_bt
+            W = self._mc_c.hidden * (2 if self._mc_c.bidirectional else 1)
+            y = torch.empty((B, T, W), dtype=torch.float32, device=self.device)
+            z = None
+            if self._mc_c.lin_layers > 0:
+                z = torch.empty((B, T, self._mc_c.lin_hidden), dtype=torch.float32, device=self.device)
+            self._check(self.lib.uvad_get_taps(self.ctx, B, T, y.data_ptr(), z.data_ptr() if z is not None else None,
+                                               self._ws.data_ptr(), self._stream()))
+            return y, z
+
+    def median_filter(self, probs: "torch.Tensor", kernel: int) -> "torch.Tensor":
+        with torch.cuda.device(self.device):
+            probs = self._dev_f32(probs, "probs")
+            B, T = probs.shape
+            out = torch.empty((B, T), dtype=torch.uint8, device=self.device)
+            self._check(self.lib.uvad_median_filter(self.ctx, probs.data_ptr(), B, T, int(kernel), out.data_ptr(), self._stream()))
+            return out
+
+    def set_timing(self, on: bool):
+        self._check(self.lib.uvad_set_timing(self.ctx, int(on)))
+
+    def timing_ms(self):
+        buf = (C.c_float * 5)()
+        self._check(self.lib.uvad_get_timing(self.ctx, buf))
+        return dict(zip(("fbank", "proj", "recurrent", "head", "total"), [float(x) for x in buf]))
+
+    # ------------------------------------------------------------------ teardown
+    def close(self):
+        if getattr(self, "ctx", None) is not None and self.ctx:
+            self.lib.uvad_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+        self._ws = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
