@@ -1,0 +1,129 @@
+"""CPU tests of the host-side mirror of the reference interface (no compute calls)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import uvad_amd
+from oracle import c_oracle as co, torch_ref as tr
+
+EXPECTED_KEYS_L0 = ["lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0",
+                    "lstm.weight_ih_l0_reverse", "lstm.weight_hh_l0_reverse", "lstm.bias_ih_l0_reverse", "lstm.bias_hh_l0_reverse"]
+
+
+def test_pyannet2_state_dict_contract():
+    m = uvad_amd.PyanNet2(encoding_dim=80)
+    m.build()
+    sd = m.state_dict()
+    keys = list(sd)
+    assert keys[:8] == EXPECTED_KEYS_L0
+    assert keys[-6:] == ["linear.0.weight", "linear.0.bias", "linear.1.weight", "linear.1.bias", "classifier.weight", "classifier.bias"]
+    assert sd["lstm.weight_ih_l0"].shape == (512, 80) and sd["lstm.weight_ih_l1"].shape == (512, 256)
+    assert sd["lstm.weight_hh_l3_reverse"].shape == (512, 128)
+    assert sd["linear.0.weight"].shape == (128, 256) and sd["classifier.weight"].shape == (1, 128)
+    assert sum(p.numel() for p in m.parameters()) == 1450369
+    assert m.encoding_dim == 80
+    assert m.hparams.lstm["batch_first"] is True and m.hparams.lstm["num_layers"] == 4
+    assert m.hparams.linear == {"hidden_size": 128, "num_layers": 2}
+    # same keys / shapes as the oracle restatement, hence as the reference class the goldens came from
+    ref = tr.TorchPyanNet2(80).state_dict()
+    assert list(ref) == keys and all(ref[k].shape == sd[k].shape for k in keys)
+    assert uvad_amd.PyanNet2().encoding_dim == 768                   # reference default
+
+
+def test_pyannet2_variants():
+    m = uvad_amd.PyanNet2(lstm={"bidirectional": False, "num_layers": 2}, linear={"num_layers": 0}, encoding_dim=64)
+    m.build()
+    assert m.classifier.in_features == 128 and not hasattr(m, "linear")
+    m2 = uvad_amd.PyanNet2(lstm={"monolithic": False}, encoding_dim=64)
+    m2.build()
+    assert "lstm.3.weight_hh_l0_reverse" in m2.state_dict()
+    with pytest.raises(RuntimeError, match="build"):
+        uvad_amd.PyanNet2(encoding_dim=64).runtime(torch.device("cuda:0"))
+    with pytest.raises(NotImplementedError):
+        uvad_amd.PyanNet()
+
+
+def test_seed_weights_equals_golden_generator_weights():
+    from uvad_amd.synth import seed_weights
+    m = uvad_amd.PyanNet2(encoding_dim=64)
+    m.build()
+    seed_weights(m, 1234, 4.0)
+    want = tr.seeded_state_dict(64, seed=1234, scale=4.0)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, want[k]), k
+
+
+def test_vadmodel_surface_and_checkpoint_roundtrip(tmp_path):
+    vm = uvad_amd.VadModel(model_name="PyanNet2", model_dict={"encoding_dim": 80})
+    assert vm.model_name == "PyanNet2" and isinstance(vm.model, uvad_amd.PyanNet2) and hasattr(vm.model, "classifier")
+    for name in ("forward", "predict_step", "_common_step", "load_from_checkpoint"):
+        assert hasattr(vm, name)
+    # Lightning-style checkpoint: {"state_dict": {"model.<key>": tensor}}
+    ck = tmp_path / "checkpoint-epoch=11.ckpt"
+    torch.save({"state_dict": {k: v for k, v in vm.state_dict().items()}, "epoch": 11}, ck)
+    assert all(k.startswith("model.") for k in vm.state_dict())
+    vm2 = uvad_amd.VadModel.load_from_checkpoint(checkpoint_path=str(ck), model_dict={"encoding_dim": 80})
+    for k, v in vm.state_dict().items():
+        assert torch.equal(v, vm2.state_dict()[k])
+    with pytest.raises(RuntimeError):   # reference pitfall (predict.py:77): default encoding_dim=768 does not fit a fbank ckpt
+        uvad_amd.VadModel.load_from_checkpoint(checkpoint_path=str(ck))
+    with pytest.raises(NotImplementedError):
+        vm.training_step({}, 0)
+
+
+def test_config_and_main_dispatch():
+    import main as entry
+    from config.config import load_config
+    cfg = load_config()
+    for key in ("task", "function", "seed", "device", "feature_extractor", "frame_shift", "model_name", "model_dict",
+                "supported_models", "checkpoint_path", "load_checkpoint", "max_duration", "predict_output_dir"):
+        assert key in cfg
+    assert cfg.model_name == "PyanNet2" and cfg.model_dict.encoding_dim == 80 and cfg.frame_shift == 0.01
+    assert dict(**cfg)["task"] == "run"                     # **config splatting, main.py:34-44
+    cfg.task = "prepare"
+    with pytest.raises(NotImplementedError):
+        entry.main(cfg)
+    cfg = load_config()
+    cfg.device = "cpu"
+    with pytest.raises(RuntimeError, match="HIP kernels only"):
+        entry.main(cfg)
+
+
+def test_reference_import_paths_resolve():
+    from src.models import PyanNet2 as A
+    from src.models.segmentation.PyanNet2 import PyanNet2 as B
+    from src.engines.vad_engine import VadModel
+    from src.utils.helper import median_filter
+    from src.scripts import predict_vad
+    assert A is B is uvad_amd.PyanNet2 and VadModel is uvad_amd.VadModel
+    assert callable(median_filter) and callable(predict_vad)
+
+
+def test_fbank_config_defaults_are_lhotse_defaults():
+    c = uvad_amd.FbankConfig(sampling_rate=16000, device="cuda")     # the reference's call, ami/utils.py:153
+    assert (c.frame_len_samples, c.frame_shift_samples, c.n_fft, c.num_filters) == (400, 160, 512, 80)
+    assert c.window_type == "povey" and c.preemph_coeff == 0.97 and c.remove_dc_offset and not c.snip_edges
+    assert c.low_freq == 20.0 and c.high_freq == -400.0 and c.dither == 0.0
+    assert abs(c.energy_floor - np.finfo(np.float32).eps) < 1e-12
+    assert uvad_amd.FbankConfig(num_mel_bins=64).num_filters == 64
+    assert uvad_amd.Fbank(c).feature_dim(16000) == 80 and uvad_amd.Fbank(c).frame_shift == 0.01
+
+
+def test_median_window_and_intervals():
+    assert uvad_amd.median_window(0.01) == 49 and uvad_amd.median_window(0.02) == 25      # helper.py:85-87
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        lab = (rng.random(rng.integers(1, 300)) < 0.5).astype(np.uint8)
+        assert uvad_amd.labels_to_intervals(lab, 0.01) == co.intervals(lab, 0.01)
+    assert uvad_amd.labels_to_intervals(np.ones(10, np.uint8), 0.01) == [(0.0, 0.09)]
+    assert uvad_amd.labels_to_intervals(np.zeros(10, np.uint8), 0.01) == []
+    assert uvad_amd.labels_to_intervals(np.array([], np.uint8), 0.01) == []
+
+
+def test_synth_is_shard_invariant():
+    from uvad_amd.synth import synth_pcm
+    full = synth_pcm(6, 8000, seed=1000)
+    assert np.array_equal(full[4:6], synth_pcm(2, 8000, seed=1000, first=4))
+    assert np.abs(full).max() <= 1.0 and full.std() > 0.05
