@@ -37,6 +37,10 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 B_PER_GPU, SECONDS, N_MELS = 256, 10.0, 64
 
 
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def classifier_flops_per_frame(F, H=128, L=4, D=2, lin=128, lin_layers=2):
     proj = 2 * (D * 4 * H * F + (L - 1) * D * 4 * H * (H * D))
     rec = 2 * (L * D * 4 * H * H)
@@ -74,8 +78,11 @@ def main():
     pcm = synth_pcm_device(B, S, seed=42, device=dev, first=rank * B)   # disjoint utterance ids per rank
     T = rt.num_frames(S)
 
+    log(f"rank {rank}/{world}: inputs ready (B={B}, T={T}); warmup")
     for _ in range(args.warmup):
         rt.forward(pcm, want_probs=False)
+    torch.cuda.synchronize(dev)
+    log("timed region")
     rt.set_timing(True)
     acc = {"fbank": 0.0, "proj": 0.0, "recurrent": 0.0, "head": 0.0, "total": 0.0}
     torch.cuda.synchronize(dev)
@@ -90,6 +97,7 @@ def main():
     elapsed = time.perf_counter() - t0
     rt.set_timing(False)
     elapsed = udist.max_over_ranks(elapsed, device=dev if world > 1 else None)
+    log(f"{args.steps} steps in {elapsed:.3f} s")
 
     frames_total = world * B * T * args.steps
     value = frames_total / elapsed
@@ -139,8 +147,11 @@ def cpu_baseline_and_error(model, rt, pcm, dev):
     """Reference CPU path (oracle/torch_ref: the reference's operator sequence on torch CPU ops) on a
     bounded sample of the SAME utterances and weights, all host cores; plus logit error GPU vs CPU."""
     from oracle import torch_ref as tr
-    cores = os.cpu_count() or 1
+    # the GPU box gives one job a share of the host (16 cores per GPU), not the whole machine:
+    # os.cpu_count() reports every core and over-subscribing them makes the torch CPU path crawl.
+    cores = int(os.environ.get("UVAD_CPU_THREADS", min(os.cpu_count() or 1, 16)))
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads")
     F = N_MELS
     cpu = tr.TorchPyanNet2(F)
     cpu.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
@@ -153,6 +164,7 @@ def cpu_baseline_and_error(model, rt, pcm, dev):
     x_all = pcm.cpu()
     run(x_all[:4])                                  # warm-up
     t = time.perf_counter(); run(x_all[:16]); dt16 = time.perf_counter() - t
+    log(f"cpu_baseline: 16 utterances took {dt16:.2f} s")
     nb = int(max(16, min(x_all.shape[0], 16 * 15.0 / max(dt16, 1e-3))))   # ~15 s of CPU work
     t = time.perf_counter(); ref = run(x_all[:nb]); dt = time.perf_counter() - t
     T = ref.shape[1]
