@@ -32,12 +32,69 @@ __device__ __forceinline__ float tanh_f(float x) {
     return __builtin_fmaf(2.0f, sigmoid_f(2.0f * x), -1.0f);
 }
 
-template <int H>
-__global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
-    constexpr int UW = H / 4;   // hidden units per wave
-    constexpr int RB = UW / 16; // 16-unit MFMA row blocks per wave
+// The cell update of one (unit, sequence) pair, cut into short stages so that the stages of row
+// block rb can be placed, in program order, between the MFMA groups of row block rb+1 (the
+// matrix pipe and the VALU issue from the same in-order stream; a stage fits the 32-cycle shadow
+// of a group of four 2-pass MFMAs).
+struct GateState {
+    f32x4 a0, a1, a2, a3, g;
+    float e0, e1, e2, e3, t, h;
+};
+constexpr float NL2E = -1.4426950408889634f;
+constexpr int GATE_STAGES = 10;
+template <int ST>
+__device__ __forceinline__ void gate_stage(GateState &S, float &c) {
+#ifdef UVAD_ABL_NOGATE   // diagnostic build (tools/lstm_ablate.hip): cell update reduced to one add
+    if constexpr (ST == 0) S.g = (S.a0 + S.a1) + (S.a2 + S.a3);
+    if constexpr (ST == 9) { S.h = S.g[0] * 1e-3f + S.g[1] * 1e-3f; c = S.g[2] + S.g[3]; }
+    return;
+#endif
+    if constexpr (ST == 0) {
+        S.g = (S.a0 + S.a1) + (S.a2 + S.a3);
+    } else if constexpr (ST == 1) {
+        S.e0 = NL2E * S.g[0]; S.e1 = NL2E * S.g[1]; S.e2 = (2.0f * NL2E) * S.g[2]; S.e3 = NL2E * S.g[3];
+    } else if constexpr (ST == 2) {
+        S.e0 = __builtin_amdgcn_exp2f(S.e0); S.e1 = __builtin_amdgcn_exp2f(S.e1);
+        S.e2 = __builtin_amdgcn_exp2f(S.e2); S.e3 = __builtin_amdgcn_exp2f(S.e3);
+    } else if constexpr (ST == 3) {
+        S.e0 += 1.0f; S.e1 += 1.0f; S.e2 += 1.0f; S.e3 += 1.0f;
+    } else if constexpr (ST == 4) {
+        S.e0 = __builtin_amdgcn_rcpf(S.e0); S.e1 = __builtin_amdgcn_rcpf(S.e1);     // i, f
+        S.e2 = __builtin_amdgcn_rcpf(S.e2); S.e3 = __builtin_amdgcn_rcpf(S.e3);     // sigma(2g), o
+    } else if constexpr (ST == 5) {
+        const float gg = __builtin_fmaf(2.0f, S.e2, -1.0f);                          // tanh(g)
+        c = __builtin_fmaf(S.e1, c, S.e0 * gg);
+        S.t = (2.0f * NL2E) * c;
+    } else if constexpr (ST == 6) {
+        S.t = __builtin_amdgcn_exp2f(S.t);
+    } else if constexpr (ST == 7) {
+        S.t += 1.0f;
+    } else if constexpr (ST == 8) {
+        S.t = __builtin_amdgcn_rcpf(S.t);
+    } else if constexpr (ST == 9) {
+        S.h = S.e3 * __builtin_fmaf(2.0f, S.t, -1.0f);                               // o * tanh(c)
+    }
+}
+template <int ST>
+__device__ __forceinline__ void gate_stages_upto(GateState &S, float &c) {   // stages [0, ST]
+    if constexpr (ST > 0) gate_stages_upto<ST - 1>(S, c);
+    gate_stage<ST>(S, c);
+}
+
+// Gate prefetch: plain loads into a ring of PD register slots (the time loop is unrolled by PD so
+// every slot is a fixed register).  An inline-asm load with hand-counted vmcnt was tried and
+// measured no faster, and it is fragile (hipcc may reuse an asm load's destination before the data
+// lands), so the compiler's own waitcnt bookkeeping is kept.
+__device__ __forceinline__ void gq_load(f32x4 &dst, const float *p) {
+    dst = *reinterpret_cast<const f32x4 *>(p);
+}
+
+template <int H, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
+    constexpr int UW = H / WAVES;   // hidden units per wave
+    constexpr int RB = UW / 16;     // 16-unit MFMA row blocks per wave
     constexpr int HS = H + 4;   // LDS row stride (floats): the 4 sequence rows land on disjoint banks
-    static_assert(RB >= 1 && UW % 16 == 0, "H must be a multiple of 64");
+    static_assert(RB >= 1 && UW % 16 == 0 && UW * WAVES == H, "H must split into 16-unit blocks over the waves");
 
     __shared__ __attribute__((aligned(16))) float hbuf[2][SEQ_TILE][HS];
 
@@ -83,75 +140,107 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
     f32x4 gq[PD][RB];
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
-        const int t = reverse ? a.T - 1 - p : p;
+        const int sp = p < a.T ? p : a.T - 1;
+        const int t = reverse ? a.T - 1 - sp : sp;
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            if (p < a.T)
-                gq[p][rb] = *reinterpret_cast<const f32x4 *>(gbase + (row0 + (size_t)t * SEQ_TILE) * a.ldg + unit[rb] * 4);
-            else
-                gq[p][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int rb = 0; rb < RB; ++rb)
+            gq_load(gq[p][rb], gbase + (row0 + (size_t)t * SEQ_TILE) * a.ldg + unit[rb] * 4);
     }
-
     float hlast[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) hlast[rb] = 0.0f;
 
-    for (int s = 0; s < a.T; ++s) {
+    // Time loop unrolled by the prefetch depth: step s uses ring slot s % PD and refills it with the
+    // gates of step s + PD, so every load lands in the register it is consumed from PD steps later
+    // (no register rotation => the compiler can wait with a counted vmcnt instead of vmcnt(0), and
+    // the h stores of the last steps stay in flight).
+    for (int s0 = 0; s0 < a.T; s0 += PD) {
+#pragma unroll
+      for (int u = 0; u < PD; ++u) {
+        const int s = s0 + u;
+        if (s >= a.T) break;   // wave-uniform
         const int t = reverse ? a.T - 1 - s : s;
-        f32x4 acc[RB][2];
+        // Pin the resident weights in the accumulator half of the unified register file: MFMA reads
+        // A operands straight from AGPRs, and VALU-addressable VGPRs stay free for h / gates.
+        // (Zero instructions: the constraint only tells the allocator where the values live here.)
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            acc[rb][0] = gq[0][rb];
-            acc[rb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        // rotate the prefetch ring and issue the load for step s + PD
+        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int p = 0; p + 1 < PD; ++p)
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) gq[p][rb] = gq[p + 1][rb];
-        {
-            const int sp = s + PD;
-            if (sp < a.T) {
-                const int tp = reverse ? a.T - 1 - sp : sp;
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
-                    gq[PD - 1][rb] = *reinterpret_cast<const f32x4 *>(gbase + (row0 + (size_t)tp * SEQ_TILE) * a.ldg + unit[rb] * 4);
-            }
-        }
+            for (int k = 0; k < H; ++k) asm volatile("" : "+a"(w[rb][k]));
 
-        // ---- gates += W_hh * h_{t-1}: 2*H MFMAs (4x4x1, 16 blocks) per wave -----------------
+        // h_{t-1} of this lane's sequence, all H values (broadcast reads: 4 distinct addresses per wave)
         const float *hb = &hbuf[s & 1][jb][0];
+        // RB > 1: every row block re-uses the values, keep them all; RB == 1: stream them (the register
+        // budget of a two-waves-per-SIMD workgroup is 256: 128 for W_hh, the rest for everything else)
+        float4 hv[RB > 1 ? H / 4 : 1];
+        if constexpr (RB > 1) {
 #pragma unroll
-        for (int kq = 0; kq < H / 4; ++kq) {
-            const float4 hv = *reinterpret_cast<const float4 *>(hb + 4 * kq);
-            const int half = kq >= H / 8 ? 1 : 0;
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                acc[rb][half] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[rb][4 * kq + 0], hv.x, acc[rb][half], 0, 0, 0);
-                acc[rb][half] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[rb][4 * kq + 1], hv.y, acc[rb][half], 0, 0, 0);
-                acc[rb][half] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[rb][4 * kq + 2], hv.z, acc[rb][half], 0, 0, 0);
-                acc[rb][half] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[rb][4 * kq + 3], hv.w, acc[rb][half], 0, 0, 0);
-            }
+            for (int kq = 0; kq < H / 4; ++kq) hv[kq] = *reinterpret_cast<const float4 *>(hb + 4 * kq);
         }
 
-        // ---- lane-local cell update ---------------------------------------------------------
         float *hn = &hbuf[(s + 1) & 1][jb][0];
         float *yrow = ybase + (row0 + (size_t)t * SEQ_TILE) * a.ldy;
+        // Row blocks one after the other, each as 4 independent accumulation chains (k mod 4):
+        // dependent MFMAs are 4 issues apart.  Everything that does not depend on the running chain
+        // is written BETWEEN its MFMA groups: the prefetch-ring rotation and the next gate load inside
+        // row block 0's chain, the cell update of row block rb inside row block rb+1's chain.
+        GateState S[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            const f32x4 g = acc[rb][0] + acc[rb][1];
-            const float ig = sigmoid_f(g[0]);
-            const float fg = sigmoid_f(g[1]);
-            const float gg = tanh_f(g[2]);
-            const float og = sigmoid_f(g[3]);
-            c[rb] = __builtin_fmaf(fg, c[rb], ig * gg);
-            const float h = og * tanh_f(c[rb]);
-            hlast[rb] = h;
-            hn[unit[rb]] = h;
-            yrow[unit[rb]] = h;
+            S[rb].a0 = gq[u][rb];
+            S[rb].a1 = S[rb].a2 = S[rb].a3 = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            if (rb > 0) __builtin_amdgcn_sched_barrier(0);   // row block rb's chain starts after rb-1's ended
+#pragma unroll
+            for (int kq = 0; kq < H / 4; ++kq) {
+                const float4 hq = RB > 1 ? hv[RB > 1 ? kq : 0] : *reinterpret_cast<const float4 *>(hb + 4 * kq);
+#ifndef UVAD_ABL_NOMFMA
+                S[rb].a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[rb][4 * kq + 0], hq.x, S[rb].a0, 0, 0, 0);
+                S[rb].a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[rb][4 * kq + 1], hq.y, S[rb].a1, 0, 0, 0);
+                S[rb].a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[rb][4 * kq + 2], hq.z, S[rb].a2, 0, 0, 0);
+                S[rb].a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[rb][4 * kq + 3], hq.w, S[rb].a3, 0, 0, 0);
+#else
+                S[rb].a0[0] += w[rb][4 * kq] * hq.x;   // keeps W and h alive without the matrix pipe
+#endif
+                if (rb == 0 && kq == H / 8) {
+                    // refill this ring slot with the gates of step min(s + PD, T - 1) (branch-free: a
+                    // redundant re-load of the last row is harmless)
+                    const int sp = s + PD < a.T ? s + PD : a.T - 1;
+                    const int tp = reverse ? a.T - 1 - sp : sp;
+#pragma unroll
+                    for (int r2 = 0; r2 < RB; ++r2)
+                        gq_load(gq[u][r2], gbase + (row0 + (size_t)tp * SEQ_TILE) * a.ldg + unit[r2] * 4);
+                }
+                if (rb > 0 && kq <= GATE_STAGES) __builtin_amdgcn_sched_barrier(0);   // pin: MFMA group | stage | MFMA group ...
+                if (rb > 0) {   // cell update of the previous row block, one stage per MFMA group
+                    if (kq == 0) gate_stage<0>(S[rb - 1], c[rb - 1]);
+                    if (kq == 1) gate_stage<1>(S[rb - 1], c[rb - 1]);
+                    if (kq == 2) gate_stage<2>(S[rb - 1], c[rb - 1]);
+                    if (kq == 3) gate_stage<3>(S[rb - 1], c[rb - 1]);
+                    if (kq == 4) gate_stage<4>(S[rb - 1], c[rb - 1]);
+                    if (kq == 5) gate_stage<5>(S[rb - 1], c[rb - 1]);
+                    if (kq == 6) gate_stage<6>(S[rb - 1], c[rb - 1]);
+                    if (kq == 7) gate_stage<7>(S[rb - 1], c[rb - 1]);
+                    if (kq == 8) gate_stage<8>(S[rb - 1], c[rb - 1]);
+                    if (kq == 9) {
+                        gate_stage<9>(S[rb - 1], c[rb - 1]);
+                        hlast[rb - 1] = S[rb - 1].h;
+                        hn[unit[rb - 1]] = S[rb - 1].h;
+                        yrow[unit[rb - 1]] = S[rb - 1].h;
+                    }
+                }
+            }
+        }
+        gate_stages_upto<GATE_STAGES - 1>(S[RB - 1], c[RB - 1]);   // the exposed tail: last row block
+        hlast[RB - 1] = S[RB - 1].h;
+        hn[unit[RB - 1]] = S[RB - 1].h;
+        yrow[unit[RB - 1]] = S[RB - 1].h;
+#ifndef UVAD_ABL_NOSYNC
         __syncthreads();
+#endif
+      }
     }
 
     if (a.hN) {
@@ -168,9 +257,11 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
 
 size_t whh_packed_elems(int H) { return (size_t)4 * H * H; }
 
+int lstm_waves(int H) { return H == 128 ? 8 : 4; }
+
 void pack_whh(const float *w_hh, int H, float *out) {
-    const int UW = H / 4, RB = UW / 16;
-    for (int wave = 0; wave < 4; ++wave)
+    const int WAVES = lstm_waves(H), UW = H / WAVES, RB = UW / 16;
+    for (int wave = 0; wave < WAVES; ++wave)
         for (int rb = 0; rb < RB; ++rb)
             for (int kq = 0; kq < H / 4; ++kq)
                 for (int lane = 0; lane < 64; ++lane)
@@ -185,9 +276,9 @@ hipError_t launch_lstm(const LstmArgs &a, hipStream_t s) {
     if (a.tiles <= 0 || a.T <= 0) return hipSuccess;
     dim3 grid(a.tiles, a.dirs);
     if (a.H == 128)
-        hipLaunchKernelGGL(lstm_rec_kernel<128>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((lstm_rec_kernel<128, 8>), grid, dim3(512), 0, s, a);
     else if (a.H == 64)
-        hipLaunchKernelGGL(lstm_rec_kernel<64>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((lstm_rec_kernel<64, 4>), grid, dim3(256), 0, s, a);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

@@ -43,6 +43,7 @@ struct LstmArgs {
 hipError_t launch_lstm(const LstmArgs &a, hipStream_t s);
 // elements of the packed W_hh image for one direction
 size_t whh_packed_elems(int H);
+int lstm_waves(int H);   // waves per recurrent workgroup (8 at H = 128: two per SIMD)
 // host-side packer: torch w_hh [4H][H] (rows i,f,g,o) -> register image
 void pack_whh(const float *w_hh, int H, float *out);
 
