@@ -18,14 +18,17 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = 36;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// Row m of A.  Rows past M (or padded sequences, b >= B) are clamped to row 0: every load in the
+// kernel is unconditional (no exec-masked branches in the K loop); what such rows produce is
+// either never stored (row >= M) or belongs to a padded sequence nobody reads.
 __device__ __forceinline__ const float *a_row_ptr(const GemmArgs &a, int m) {
-    if (m >= a.M) return nullptr;
+    if (m >= a.M) return a.A;
     if (a.a_mode == 0) return a.A + (size_t)m * a.lda;
     const int per_tile = a.T * SEQ_TILE;
     const int tile = m / per_tile, rem = m - tile * per_tile;
     const int t = rem / SEQ_TILE, j = rem - t * SEQ_TILE;
     const int b = tile * SEQ_TILE + j;
-    if (b >= a.B) return nullptr;
+    if (b >= a.B) return a.A;
     return a.A + ((size_t)b * a.T + t) * a.lda;
 }
 
@@ -45,99 +48,117 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a, int mt, int n
 
     // staging assignment: 8 float4 per 32-float row, 32 rows per pass, 4 passes per operand
     const int srow = tid >> 3, skq = tid & 7;
-    const float *ap[4];
-    const float *bp[4];
+    const float *ap0 = a_row_ptr(a, R0 + srow) + skq * 4;
+    const float *ap1 = a_row_ptr(a, R0 + srow + 32) + skq * 4;
+    const float *ap2 = a_row_ptr(a, R0 + srow + 64) + skq * 4;
+    const float *ap3 = a_row_ptr(a, R0 + srow + 96) + skq * 4;
+    // W rows are zero-padded to ldw >= nk*BK; rows past N are clamped to row 0 (never stored)
+    const int n0 = C0 + srow;
+    const float *bp0 = a.W + (size_t)(n0 < a.N ? n0 : 0) * a.ldw + skq * 4;
+    const float *bp1 = a.W + (size_t)(n0 + 32 < a.N ? n0 + 32 : 0) * a.ldw + skq * 4;
+    const float *bp2 = a.W + (size_t)(n0 + 64 < a.N ? n0 + 64 : 0) * a.ldw + skq * 4;
+    const float *bp3 = a.W + (size_t)(n0 + 96 < a.N ? n0 + 96 : 0) * a.ldw + skq * 4;
+
+    f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ap[i] = a_row_ptr(a, R0 + srow + 32 * i);
-        const int n = C0 + srow + 32 * i;
-        bp[i] = n < a.N ? a.W + (size_t)n * a.K : nullptr;
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    // A columns past K (only in the last K-step when K % 32 != 0) re-read column block 0: finite
+    // values that meet zero weights.
+#define UVAD_GLOAD(k0)                                                        \
+    {                                                                         \
+        const int ka_ = ((k0) + skq * 4 < a.K) ? (k0) : -skq * 4;             \
+        ra0 = *reinterpret_cast<const float4 *>(ap0 + ka_);                   \
+        ra1 = *reinterpret_cast<const float4 *>(ap1 + ka_);                   \
+        ra2 = *reinterpret_cast<const float4 *>(ap2 + ka_);                   \
+        ra3 = *reinterpret_cast<const float4 *>(ap3 + ka_);                   \
+        rb0 = *reinterpret_cast<const float4 *>(bp0 + (k0));                  \
+        rb1 = *reinterpret_cast<const float4 *>(bp1 + (k0));                  \
+        rb2 = *reinterpret_cast<const float4 *>(bp2 + (k0));                  \
+        rb3 = *reinterpret_cast<const float4 *>(bp3 + (k0));                  \
+    }
+    float *as_w = &As[srow * LDS_LD + skq * 4], *bs_w = &Bs[srow * LDS_LD + skq * 4];
+#define UVAD_LSTORE()                                                         \
+    {                                                                         \
+        *reinterpret_cast<float4 *>(as_w) = ra0;                              \
+        *reinterpret_cast<float4 *>(as_w + 32 * LDS_LD) = ra1;                \
+        *reinterpret_cast<float4 *>(as_w + 64 * LDS_LD) = ra2;                \
+        *reinterpret_cast<float4 *>(as_w + 96 * LDS_LD) = ra3;                \
+        *reinterpret_cast<float4 *>(bs_w) = rb0;                              \
+        *reinterpret_cast<float4 *>(bs_w + 32 * LDS_LD) = rb1;                \
+        *reinterpret_cast<float4 *>(bs_w + 64 * LDS_LD) = rb2;                \
+        *reinterpret_cast<float4 *>(bs_w + 96 * LDS_LD) = rb3;                \
     }
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float4 ra[4], rb[4];
-    auto gload = [&](int k0) {
-        const int k = k0 + skq * 4;
-        const bool kin = k < a.K;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = (kin && ap[i]) ? *reinterpret_cast<const float4 *>(ap[i] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[i] = (kin && bp[i]) ? *reinterpret_cast<const float4 *>(bp[i] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4 *>(&As[(srow + 32 * i) * LDS_LD + skq * 4]) = ra[i];
-            *reinterpret_cast<float4 *>(&Bs[(srow + 32 * i) * LDS_LD + skq * 4]) = rb[i];
-        }
-    };
-
     const int nk = (a.K + BK - 1) / BK;
-    gload(0);
-    lstore();
+    UVAD_GLOAD(0)
+    UVAD_LSTORE()
     __syncthreads();
 
     const int fr = lane & 31, fh = lane >> 5;
+    const float *as_r = &As[(wr * 64 + fr) * LDS_LD + fh * 4], *bs_r = &Bs[(wc * 64 + fr) * LDS_LD + fh * 4];
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+        if (kt + 1 < nk) UVAD_GLOAD((kt + 1) * BK)
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
-            float4 av[2], bv[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                av[i] = *reinterpret_cast<const float4 *>(&As[(wr * 64 + i * 32 + fr) * LDS_LD + kc * 8 + fh * 4]);
-                bv[i] = *reinterpret_cast<const float4 *>(&Bs[(wc * 64 + i * 32 + fr) * LDS_LD + kc * 8 + fh * 4]);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
-                }
+            const float4 a0 = *reinterpret_cast<const float4 *>(as_r + kc * 8);
+            const float4 a1 = *reinterpret_cast<const float4 *>(as_r + 32 * LDS_LD + kc * 8);
+            const float4 b0 = *reinterpret_cast<const float4 *>(bs_r + kc * 8);
+            const float4 b1 = *reinterpret_cast<const float4 *>(bs_r + 32 * LDS_LD + kc * 8);
+#define UVAD_MFMA4(ACC, AV, BV)                                                   \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.x, BV.x, ACC, 0, 0, 0);         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.y, BV.y, ACC, 0, 0, 0);         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.z, BV.z, ACC, 0, 0, 0);         \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.w, BV.w, ACC, 0, 0, 0);
+            UVAD_MFMA4(acc00, a0, b0)
+            UVAD_MFMA4(acc01, a0, b1)
+            UVAD_MFMA4(acc10, a1, b0)
+            UVAD_MFMA4(acc11, a1, b1)
         }
         __syncthreads();
         if (kt + 1 < nk) {
-            lstore();
+            UVAD_LSTORE()
             __syncthreads();
         }
     }
 
     // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = C0 + wc * 64 + j * 32 + fr;
-        if (col >= a.N) continue;
-        const float bias = a.bias ? a.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = R0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (row < a.M) {
-                    float v = acc[i][j][r] + bias;
-                    if (a.act == 1) v = v >= 0.f ? v : a.leaky_slope * v;
-                    a.C[(size_t)row * a.ldc + col] = v;
-                }
-            }
-        }
+    const bool full = R0 + BM <= a.M && C0 + BN <= a.N;   // block-uniform: interior tiles store unguarded
+#define UVAD_EPILOGUE(ACC, I, J)                                                                     \
+    {                                                                                                \
+        const int col = C0 + wc * 64 + (J) * 32 + fr;                                                \
+        const int rbase = R0 + wr * 64 + (I) * 32 + 4 * fh;                                          \
+        const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;                                \
+        float *crow = a.C + (size_t)rbase * a.ldc + col;                                             \
+        float v[16];                                                                                 \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
+            v[r] = ACC[r] + bias;                                                                    \
+            if (a.act == 1) v[r] = v[r] >= 0.f ? v[r] : a.leaky_slope * v[r];                        \
+        }                                                                                            \
+        if (full) {                                                                                  \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                           \
+                crow[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldc] = v[r];                               \
+        } else {                                                                                     \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+                const int dr = (r & 3) + 8 * (r >> 2);                                               \
+                if (rbase + dr < a.M && col < a.N) crow[(size_t)dr * a.ldc] = v[r];                  \
+            }                                                                                        \
+        }                                                                                            \
     }
+    UVAD_EPILOGUE(acc00, 0, 0)
+    UVAD_EPILOGUE(acc01, 0, 1)
+    UVAD_EPILOGUE(acc10, 1, 0)
+    UVAD_EPILOGUE(acc11, 1, 1)
 }
 
 }  // namespace
 
+int gemm_padded_k(int K) { return (K + BK - 1) / BK * BK; }
+
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
+    if (a.ldw < gemm_padded_k(a.K)) return hipErrorInvalidValue;
     const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
     const int grid = ((mt + 7) / 8) * 8 * nt;
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(grid), dim3(256), 0, s, a, mt, nt);

@@ -86,8 +86,18 @@ __device__ __forceinline__ void gate_stages_upto(GateState &S, float &c) {   // 
 // measured no faster, and it is fragile (hipcc may reuse an asm load's destination before the data
 // lands), so the compiler's own waitcnt bookkeeping is kept.
 __device__ __forceinline__ void gq_load(f32x4 &dst, const float *p) {
+#ifdef UVAD_ABL_NOGMEM   // diagnostic: no global traffic inside the time loop
+    dst = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
+    (void)p;
+#else
     dst = *reinterpret_cast<const f32x4 *>(p);
+#endif
 }
+#ifdef UVAD_ABL_NOGMEM
+#define UVAD_YSTORE(ptr, v) asm volatile("" ::"v"(ptr), "v"(v))
+#else
+#define UVAD_YSTORE(ptr, v) (*(ptr) = (v))
+#endif
 
 template <int H, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
@@ -149,6 +159,20 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
     float hlast[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) hlast[rb] = 0.0f;
+#ifdef UVAD_STAMP   // diagnostic build (tools/lstm_ablate.hip): per-wave cycle shares of a step
+    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0;
+#define UVAD_STAMP_AT(i)                                                                          \
+    {                                                                                             \
+        unsigned long long t_;                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (st_prev) st_acc[i] += t_ - st_prev;                                                   \
+        st_prev = t_;                                                                             \
+    }
+#else
+#define UVAD_STAMP_AT(i)
+#endif
 
     // Time loop unrolled by the prefetch depth: step s uses ring slot s % PD and refills it with the
     // gates of step s + PD, so every load lands in the register it is consumed from PD steps later
@@ -172,11 +196,18 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
         const float *hb = &hbuf[s & 1][jb][0];
         // RB > 1: every row block re-uses the values, keep them all; RB == 1: stream them (the register
         // budget of a two-waves-per-SIMD workgroup is 256: 128 for W_hh, the rest for everything else)
-        float4 hv[RB > 1 ? H / 4 : 1];
-        if constexpr (RB > 1) {
+        // With RB == 1 they are streamed through a ring of HR slots, refilled right after use, so that
+        // HR LDS reads stay in flight ahead of the MFMA groups (LDS latency under 8 reading waves is
+        // several MFMA groups long; a read issued one group ahead stalls the matrix pipe).
+        constexpr int HR = RB > 1 ? H / 4 : 16;
+        float4 hv[HR];
+#ifdef UVAD_ABL_NOLDSREAD   // diagnostic: no h reads at all (results meaningless)
 #pragma unroll
-            for (int kq = 0; kq < H / 4; ++kq) hv[kq] = *reinterpret_cast<const float4 *>(hb + 4 * kq);
-        }
+        for (int kq = 0; kq < HR; ++kq) hv[kq] = make_float4(c[0], hlast[0], c[0] * 0.5f, hlast[0] * 0.5f);
+#else
+#pragma unroll
+        for (int kq = 0; kq < HR; ++kq) hv[kq] = *reinterpret_cast<const float4 *>(hb + 4 * kq);
+#endif
 
         float *hn = &hbuf[(s + 1) & 1][jb][0];
         float *yrow = ybase + (row0 + (size_t)t * SEQ_TILE) * a.ldy;
@@ -185,6 +216,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
         // is written BETWEEN its MFMA groups: the prefetch-ring rotation and the next gate load inside
         // row block 0's chain, the cell update of row block rb inside row block rb+1's chain.
         GateState S[RB];
+        UVAD_STAMP_AT(3)   // [3] = barrier wait + loop top
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             S[rb].a0 = gq[u][rb];
@@ -195,7 +227,10 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
             if (rb > 0) __builtin_amdgcn_sched_barrier(0);   // row block rb's chain starts after rb-1's ended
 #pragma unroll
             for (int kq = 0; kq < H / 4; ++kq) {
-                const float4 hq = RB > 1 ? hv[RB > 1 ? kq : 0] : *reinterpret_cast<const float4 *>(hb + 4 * kq);
+                const float4 hq = hv[kq % HR];
+#ifndef UVAD_ABL_NOLDSREAD
+                if (RB == 1 && kq + HR < H / 4) hv[kq % HR] = *reinterpret_cast<const float4 *>(hb + 4 * (kq + HR));
+#endif
 #ifndef UVAD_ABL_NOMFMA
                 S[rb].a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[rb][4 * kq + 0], hq.x, S[rb].a0, 0, 0, 0);
                 S[rb].a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[rb][4 * kq + 1], hq.y, S[rb].a1, 0, 0, 0);
@@ -228,21 +263,41 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
                         gate_stage<9>(S[rb - 1], c[rb - 1]);
                         hlast[rb - 1] = S[rb - 1].h;
                         hn[unit[rb - 1]] = S[rb - 1].h;
-                        yrow[unit[rb - 1]] = S[rb - 1].h;
+                        UVAD_YSTORE(&yrow[unit[rb - 1]], S[rb - 1].h);
                     }
                 }
             }
         }
+        if constexpr (RB == 1) {
+            // keep HR LDS reads in flight: [HR reads] then [4 MFMA + 1 read] per group (without this the
+            // scheduler sinks every read to one group before its use and the chain stalls on LDS latency)
+            __builtin_amdgcn_sched_group_barrier(0x100, HR, 0);
+#pragma unroll
+            for (int i = 0; i < H / 4 - HR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * HR, 0);
+        }
+        UVAD_STAMP_AT(0)   // [0] = h reads + MFMA chains
         gate_stages_upto<GATE_STAGES - 1>(S[RB - 1], c[RB - 1]);   // the exposed tail: last row block
         hlast[RB - 1] = S[RB - 1].h;
         hn[unit[RB - 1]] = S[RB - 1].h;
-        yrow[unit[RB - 1]] = S[RB - 1].h;
+        UVAD_YSTORE(&yrow[unit[RB - 1]], S[RB - 1].h);
+        UVAD_STAMP_AT(1)   // [1] = cell update + h write/store
 #ifndef UVAD_ABL_NOSYNC
         __syncthreads();
 #endif
       }
     }
 
+#ifdef UVAD_STAMP
+    if (lane == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.hN) + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave) * 4;
+        for (int i = 0; i < 4; ++i) o[i] = st_acc[i];
+    }
+    return;
+#endif
     if (a.hN) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {

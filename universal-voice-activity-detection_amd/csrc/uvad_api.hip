@@ -235,7 +235,8 @@ int uvad_finalize(uvad_ctx *c) {
     c->layers.assign(m.num_layers, LayerDev());
     for (int k = 0; k < m.num_layers; ++k) {
         const int in = k == 0 ? m.in_dim : H * D;
-        std::vector<float> wp((size_t)D * 4 * H * in), bp((size_t)D * 4 * H), hh((size_t)D * whh_packed_elems(H));
+        const int inp = gemm_padded_k(in);   // rows zero-padded to the GEMM's K-step
+        std::vector<float> wp((size_t)D * 4 * H * inp, 0.0f), bp((size_t)D * 4 * H), hh((size_t)D * whh_packed_elems(H));
         for (int d = 0; d < D; ++d) {
             const std::string suf = "_l" + std::to_string(k) + (d ? "_reverse" : "");
             const HostTensor *wih = get("lstm.weight_ih" + suf), *whh = get("lstm.weight_hh" + suf);
@@ -248,7 +249,7 @@ int uvad_finalize(uvad_ctx *c) {
             for (int u = 0; u < H; ++u)
                 for (int g = 0; g < 4; ++g) {
                     const size_t dst = (size_t)d * 4 * H + (size_t)u * 4 + g, src = (size_t)g * H + u;
-                    std::memcpy(&wp[dst * in], &wih->data[src * in], sizeof(float) * in);
+                    std::memcpy(&wp[dst * inp], &wih->data[src * in], sizeof(float) * in);
                     bp[dst] = bih->data[src] + bhh->data[src];
                 }
             pack_whh(whh->data.data(), H, &hh[(size_t)d * whh_packed_elems(H)]);
@@ -269,7 +270,10 @@ int uvad_finalize(uvad_ctx *c) {
         if (!expect_shape(*w, {m.lin_hidden, prev}) || !expect_shape(*b, {m.lin_hidden}))
             return fail(c, UVAD_E_ARG, "linear." + std::to_string(j) + " shape mismatch");
         int r;
-        if ((r = dev_upload(c, w->data.data(), w->data.size(), &c->lin_w[j]))) return r;
+        const int prevp = gemm_padded_k(prev);
+        std::vector<float> wpad((size_t)m.lin_hidden * prevp, 0.0f);
+        for (int o = 0; o < m.lin_hidden; ++o) std::memcpy(&wpad[(size_t)o * prevp], &w->data[(size_t)o * prev], sizeof(float) * prev);
+        if ((r = dev_upload(c, wpad.data(), wpad.size(), &c->lin_w[j]))) return r;
         if ((r = dev_upload(c, b->data.data(), b->data.size(), &c->lin_b[j]))) return r;
         prev = m.lin_hidden;
     }
@@ -336,7 +340,7 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
     for (int k = 0; k < m.num_layers; ++k) {
         const LayerDev &L = c->layers[k];
         GemmArgs g{};
-        g.W = L.w_ih; g.bias = L.bias; g.C = G; g.M = (int)w.M; g.N = N4; g.K = L.in; g.ldc = N4;
+        g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.bias = L.bias; g.C = G; g.M = (int)w.M; g.N = N4; g.K = L.in; g.ldc = N4;
         g.B = B; g.T = T; g.act = 0; g.leaky_slope = 0.f;
         if (k == 0) { g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1; }
         else { g.A = Y[(k - 1) & 1]; g.lda = w.Wd; g.a_mode = 0; }
@@ -354,7 +358,7 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
     int curw = w.Wd;
     for (int j = 0; j < m.lin_layers; ++j) {
         GemmArgs g{};
-        g.A = cur; g.lda = curw; g.a_mode = 0; g.W = c->lin_w[j]; g.bias = c->lin_b[j]; g.C = Z[j & 1];
+        g.A = cur; g.lda = curw; g.a_mode = 0; g.W = c->lin_w[j]; g.ldw = gemm_padded_k(curw); g.bias = c->lin_b[j]; g.C = Z[j & 1];
         g.M = (int)w.M; g.N = m.lin_hidden; g.K = curw; g.ldc = m.lin_hidden; g.B = B; g.T = T;
         g.act = 1; g.leaky_slope = m.leaky_slope;
         HIPCHK(c, launch_gemm(g, s));

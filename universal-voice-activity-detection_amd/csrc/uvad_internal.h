@@ -15,7 +15,9 @@ constexpr int SEQ_TILE = 4;
 // C[M][ldc] (cols [0,N)) = act( A[M][K] * W[N][K]^T + bias[N] ), exact f32 on v_mfma_f32_32x32x2_f32.
 struct GemmArgs {
     const float *A;      // activations
-    const float *W;      // [N][K] row-major (torch Linear / LSTM weight layout, rows possibly permuted)
+    const float *W;      // [N][ldw] row-major (torch Linear / LSTM weight layout, rows possibly permuted),
+                         // each row zero-padded to ldw = gemm_padded_k(K) floats
+    int ldw;
     const float *bias;   // [N] or nullptr
     float *C;
     int M, N, K;
@@ -28,6 +30,7 @@ struct GemmArgs {
     int act;
 };
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t s);
+int gemm_padded_k(int K);   // K rounded up to the kernel's K-step
 
 // ---- lstm.hip -----------------------------------------------------------------------------
 // One layer, all directions: grid (tiles, dirs).  G holds x_t*W_ih^T + b_ih + b_hh with column
