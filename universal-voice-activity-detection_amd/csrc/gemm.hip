@@ -16,6 +16,11 @@ namespace uvad {
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = 36;
+#ifdef UVAD_GEMM_ABL_NOSTORE   // diagnostic build (tools/gemm_ablate.hip): interior tiles skip their stores
+#define UVAD_GEMM_ABL_NOSTORE_COND full
+#else
+#define UVAD_GEMM_ABL_NOSTORE_COND false
+#endif
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // Row m of A.  Rows past M (or padded sequences, b >= B) are clamped to row 0: every load in the
@@ -106,15 +111,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a, int mt, int n
             const float4 a1 = *reinterpret_cast<const float4 *>(as_r + 32 * LDS_LD + kc * 8);
             const float4 b0 = *reinterpret_cast<const float4 *>(bs_r + kc * 8);
             const float4 b1 = *reinterpret_cast<const float4 *>(bs_r + 32 * LDS_LD + kc * 8);
-#define UVAD_MFMA4(ACC, AV, BV)                                                   \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.x, BV.x, ACC, 0, 0, 0);         \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.y, BV.y, ACC, 0, 0, 0);         \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.z, BV.z, ACC, 0, 0, 0);         \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.w, BV.w, ACC, 0, 0, 0);
-            UVAD_MFMA4(acc00, a0, b0)
-            UVAD_MFMA4(acc01, a0, b1)
-            UVAD_MFMA4(acc10, a1, b0)
-            UVAD_MFMA4(acc11, a1, b1)
+            // the four accumulators are visited round-robin so consecutive MFMAs are independent
+#define UVAD_MFMA_E(E)                                                               \
+    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.E, b0.E, acc00, 0, 0, 0);        \
+    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.E, b1.E, acc01, 0, 0, 0);        \
+    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.E, b0.E, acc10, 0, 0, 0);        \
+    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.E, b1.E, acc11, 0, 0, 0);
+            UVAD_MFMA_E(x)
+            UVAD_MFMA_E(y)
+            UVAD_MFMA_E(z)
+            UVAD_MFMA_E(w)
         }
         __syncthreads();
         if (kt + 1 < nk) {
@@ -136,7 +142,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a, int mt, int n
             v[r] = ACC[r] + bias;                                                                    \
             if (a.act == 1) v[r] = v[r] >= 0.f ? v[r] : a.leaky_slope * v[r];                        \
         }                                                                                            \
-        if (full) {                                                                                  \
+        if (UVAD_GEMM_ABL_NOSTORE_COND) {                                                            \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(v[r]));             \
+        } else if (full) {                                                                           \
             _Pragma("unroll") for (int r = 0; r < 16; ++r)                                           \
                 crow[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldc] = v[r];                               \
         } else {                                                                                     \
