@@ -137,6 +137,14 @@ int uvad_stream_step(uvad_ctx *, const float *d_pcm_chunk, int B, int chunk, voi
 int uvad_median_filter(uvad_ctx *, const float *d_probs, int B, int T, int kernel, uint8_t *d_labels,
                        void *stream);
 
+/* Which kernel runs the time-parallel contractions (input projections, feed-forward layers):
+ *   0  exact f32: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain, bit-compatible with f32 FMA arithmetic;
+ *   1  (default) f32-accurate on the bf16 matrix cores: operands split exactly into three bf16 pieces,
+ *      six v_mfma_f32_32x32x16_bf16 per product term set, f32 accumulation (2.7x the f32 MFMA rate;
+ *      dropped terms <= 2^-23 relative).  Both are held to the same 1e-4 logit bound by the tests.
+ * The environment variable UVAD_GEMM=f32 selects 0 at uvad_create. */
+int uvad_set_gemm_mode(uvad_ctx *, int mode);
+
 /* Per-stage device timing of the most recent uvad_forward/uvad_classify made with timing enabled
  * (uvad_set_timing(ctx, 1) inserts hipEvents on the caller's stream; not graph-capturable while
  * enabled).  ms[0..4] = fbank, input projections, recurrences, feed-forward+classifier, total.

@@ -51,6 +51,7 @@ SIGNATURES = {
     "uvad_stream_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "uvad_median_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "uvad_set_gemm_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "uvad_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "uvad_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "uvad_last_error": (C.c_char_p, [C.c_void_p]),

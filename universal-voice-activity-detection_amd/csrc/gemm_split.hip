@@ -1,0 +1,227 @@
+// gemm_split.hip -- f32-accurate GEMM on the bf16 matrix cores ("bf16x6"): same contract as
+// gemm.hip (C = act(A * W^T + b), A f32 in HBM), 2.7x the f32-MFMA rate.
+//
+// Each f32 operand is written EXACTLY as the sum of three bf16 pieces (8 + 8 + 8 mantissa bits):
+//     x = x1 + x2 + x3,   x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
+// and the product keeps every term down to 2^-16 of the leading one:
+//     a*w ~= a1w1 + (a1w2 + a2w1) + (a1w3 + a3w1 + a2w2)          (dropped: <= 2^-23 relative)
+// bf16 x bf16 products are exact in f32 and v_mfma_f32_32x32x16_bf16 accumulates in f32, so the
+// result carries f32-level error (tests/test_gpu_parity.py holds it to the same 1e-4 logit bound as
+// the exact kernel) at 6 MFMAs of 16x the f32 rate: 16/6 = 2.67x.  Weights are split once on the
+// host (uvad_finalize); activations are split on the fly while they are staged into LDS.
+//
+// Tile: 128x128 per 256-thread workgroup, 2x2 waves x 2x2 accumulators of 32x32, K-step 32.
+// LDS: 3 planes x (A, W) x 128 rows x 40 bf16 (80-byte rows: conflict-free ds_read_b128 fragments).
+#include "uvad_internal.h"
+
+namespace uvad {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDH = 40;   // LDH: LDS row stride in bf16 elements
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+__device__ __forceinline__ const float *a_row_ptr(const GemmArgs &a, int m) {
+    if (m >= a.M) return a.A;
+    if (a.a_mode == 0) return a.A + (size_t)m * a.lda;
+    const int per_tile = a.T * SEQ_TILE;
+    const int tile = m / per_tile, rem = m - tile * per_tile;
+    const int t = rem / SEQ_TILE, j = rem - t * SEQ_TILE;
+    const int b = tile * SEQ_TILE + j;
+    if (b >= a.B) return a.A;
+    return a.A + ((size_t)b * a.T + t) * a.lda;
+}
+
+__device__ __forceinline__ unsigned short bf16_bits(float x) {
+    const __bf16 h = (__bf16)x;   // round to nearest even (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) {
+    return __builtin_bit_cast(float, (unsigned)b << 16);
+}
+// (x, y) -> three packed bf16 pairs; each float is the exact sum of its three pieces (up to the last
+// piece's rounding at 2^-25).  Everything stays in 32-bit registers (no sub-dword temporaries).
+__device__ __forceinline__ void split3_pair(float x, float y, unsigned &p1, unsigned &p2, unsigned &p3) {
+    const unsigned x1 = bf16_bits(x), y1 = bf16_bits(y);
+    const float rx1 = x - bf16_to_f32((unsigned short)x1), ry1 = y - bf16_to_f32((unsigned short)y1);
+    const unsigned x2 = bf16_bits(rx1), y2 = bf16_bits(ry1);
+    const float rx2 = rx1 - bf16_to_f32((unsigned short)x2), ry2 = ry1 - bf16_to_f32((unsigned short)y2);
+    const unsigned x3 = bf16_bits(rx2), y3 = bf16_bits(ry2);
+    p1 = x1 | (y1 << 16);
+    p2 = x2 | (y2 << 16);
+    p3 = x3 | (y3 << 16);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmArgs a, int mt, int nt) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[3][BM * LDH];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3][BN * LDH];
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int m_tile = (idx / nt) * 8 + xcd, n_tile = idx % nt;
+    if (m_tile >= mt) return;
+    const int R0 = m_tile * BM, C0 = n_tile * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // A staging: 8 float4 per 32-float row, 32 rows per pass, 4 passes
+    const int srow = tid >> 3, skq = tid & 7;
+    const float *ap0 = a_row_ptr(a, R0 + srow) + skq * 4;
+    const float *ap1 = a_row_ptr(a, R0 + srow + 32) + skq * 4;
+    const float *ap2 = a_row_ptr(a, R0 + srow + 64) + skq * 4;
+    const float *ap3 = a_row_ptr(a, R0 + srow + 96) + skq * 4;
+    // W staging (pre-split bf16 planes [3][N][ldw]): thread = (row, 16-element half)
+    const int brow = tid >> 1, bhalf = tid & 1;
+    const int nrow = C0 + brow < a.N ? C0 + brow : 0;
+    const size_t plane = (size_t)a.N * a.ldw;
+    const unsigned short *wp = a.Wsplit + (size_t)nrow * a.ldw + bhalf * 16;
+
+    f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+
+    float4 ra0, ra1, ra2, ra3;
+    uint4 rw00, rw01, rw10, rw11, rw20, rw21;
+#define UVAD_GLOAD(k0)                                                                  \
+    {                                                                                   \
+        const int ka_ = ((k0) + skq * 4 < a.K) ? (k0) : -skq * 4;                       \
+        ra0 = *reinterpret_cast<const float4 *>(ap0 + ka_);                             \
+        ra1 = *reinterpret_cast<const float4 *>(ap1 + ka_);                             \
+        ra2 = *reinterpret_cast<const float4 *>(ap2 + ka_);                             \
+        ra3 = *reinterpret_cast<const float4 *>(ap3 + ka_);                             \
+        rw00 = *reinterpret_cast<const uint4 *>(wp + (k0));                             \
+        rw01 = *reinterpret_cast<const uint4 *>(wp + (k0) + 8);                         \
+        rw10 = *reinterpret_cast<const uint4 *>(wp + plane + (k0));                     \
+        rw11 = *reinterpret_cast<const uint4 *>(wp + plane + (k0) + 8);                 \
+        rw20 = *reinterpret_cast<const uint4 *>(wp + 2 * plane + (k0));                 \
+        rw21 = *reinterpret_cast<const uint4 *>(wp + 2 * plane + (k0) + 8);             \
+    }
+#define UVAD_SPLIT_STORE(RA, ROW)                                                       \
+    {                                                                                   \
+        uint2 q1, q2, q3;                                                               \
+        split3_pair(RA.x, RA.y, q1.x, q2.x, q3.x);                                      \
+        split3_pair(RA.z, RA.w, q1.y, q2.y, q3.y);                                      \
+        *reinterpret_cast<uint2 *>(&As[0][(ROW) * LDH + skq * 4]) = q1;                 \
+        *reinterpret_cast<uint2 *>(&As[1][(ROW) * LDH + skq * 4]) = q2;                 \
+        *reinterpret_cast<uint2 *>(&As[2][(ROW) * LDH + skq * 4]) = q3;                 \
+    }
+#define UVAD_LSTORE()                                                                   \
+    {                                                                                   \
+        UVAD_SPLIT_STORE(ra0, srow)                                                     \
+        UVAD_SPLIT_STORE(ra1, srow + 32)                                                \
+        UVAD_SPLIT_STORE(ra2, srow + 64)                                                \
+        UVAD_SPLIT_STORE(ra3, srow + 96)                                                \
+        *reinterpret_cast<uint4 *>(&Bs[0][brow * LDH + bhalf * 16]) = rw00;             \
+        *reinterpret_cast<uint4 *>(&Bs[0][brow * LDH + bhalf * 16 + 8]) = rw01;         \
+        *reinterpret_cast<uint4 *>(&Bs[1][brow * LDH + bhalf * 16]) = rw10;             \
+        *reinterpret_cast<uint4 *>(&Bs[1][brow * LDH + bhalf * 16 + 8]) = rw11;         \
+        *reinterpret_cast<uint4 *>(&Bs[2][brow * LDH + bhalf * 16]) = rw20;             \
+        *reinterpret_cast<uint4 *>(&Bs[2][brow * LDH + bhalf * 16 + 8]) = rw21;         \
+    }
+
+    const int nk = (a.K + BK - 1) / BK;
+    UVAD_GLOAD(0)
+    UVAD_LSTORE()
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int a_off = (wr * 64 + fr) * LDH + fh * 8, b_off = (wc * 64 + fr) * LDH + fh * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) UVAD_GLOAD((kt + 1) * BK)
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                fa[0][p] = *reinterpret_cast<const bf16x8 *>(&As[p][a_off + s * 16]);
+                fa[1][p] = *reinterpret_cast<const bf16x8 *>(&As[p][a_off + 32 * LDH + s * 16]);
+                fb[0][p] = *reinterpret_cast<const bf16x8 *>(&Bs[p][b_off + s * 16]);
+                fb[1][p] = *reinterpret_cast<const bf16x8 *>(&Bs[p][b_off + 32 * LDH + s * 16]);
+            }
+            // smallest terms first: (a1w3 + a3w1 + a2w2), (a1w2 + a2w1), a1w1
+#define UVAD_MM(ACC, I, J, PA, PB) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[I][PA], fb[J][PB], ACC, 0, 0, 0);
+#define UVAD_SIX(ACC, I, J)                                                              \
+    UVAD_MM(ACC, I, J, 0, 2) UVAD_MM(ACC, I, J, 2, 0) UVAD_MM(ACC, I, J, 1, 1)           \
+    UVAD_MM(ACC, I, J, 0, 1) UVAD_MM(ACC, I, J, 1, 0) UVAD_MM(ACC, I, J, 0, 0)
+            UVAD_SIX(acc00, 0, 0)
+            UVAD_SIX(acc01, 0, 1)
+            UVAD_SIX(acc10, 1, 0)
+            UVAD_SIX(acc11, 1, 1)
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            UVAD_LSTORE()
+            __syncthreads();
+        }
+    }
+
+    // epilogue: identical to gemm.hip (C/D map of the 32x32 MFMA is dtype-independent)
+    const bool full = R0 + BM <= a.M && C0 + BN <= a.N;
+#define UVAD_EPILOGUE(ACC, I, J)                                                                     \
+    {                                                                                                \
+        const int col = C0 + wc * 64 + (J) * 32 + fr;                                                \
+        const int rbase = R0 + wr * 64 + (I) * 32 + 4 * fh;                                          \
+        const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;                                \
+        float *crow = a.C + (size_t)rbase * a.ldc + col;                                             \
+        float v[16];                                                                                 \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
+            v[r] = ACC[r] + bias;                                                                    \
+            if (a.act == 1) v[r] = v[r] >= 0.f ? v[r] : a.leaky_slope * v[r];                        \
+        }                                                                                            \
+        if (full) {                                                                                  \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                           \
+                crow[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldc] = v[r];                               \
+        } else {                                                                                     \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+                const int dr = (r & 3) + 8 * (r >> 2);                                               \
+                if (rbase + dr < a.M && col < a.N) crow[(size_t)dr * a.ldc] = v[r];                  \
+            }                                                                                        \
+        }                                                                                            \
+    }
+    UVAD_EPILOGUE(acc00, 0, 0)
+    UVAD_EPILOGUE(acc01, 0, 1)
+    UVAD_EPILOGUE(acc10, 1, 0)
+    UVAD_EPILOGUE(acc11, 1, 1)
+}
+
+}  // namespace
+
+// host: f32 [N][ldw] (rows already zero-padded) -> three bf16 planes [3][N][ldw]
+void split_weights_bf16x3(const float *w, size_t n, unsigned short *out) {
+    auto rne = [](float x) -> unsigned short {
+        unsigned u;
+        __builtin_memcpy(&u, &x, 4);
+        if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);   // inf / nan: truncate
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (unsigned short)(u >> 16);
+    };
+    auto up = [](unsigned short b) -> float {
+        const unsigned u = (unsigned)b << 16;
+        float f;
+        __builtin_memcpy(&f, &u, 4);
+        return f;
+    };
+    for (size_t i = 0; i < n; ++i) {
+        const float x = w[i];
+        const unsigned short p1 = rne(x);
+        const float r1 = x - up(p1);
+        const unsigned short p2 = rne(r1);
+        const float r2 = r1 - up(p2);
+        out[i] = p1;
+        out[n + i] = p2;
+        out[2 * n + i] = rne(r2);
+    }
+}
+
+hipError_t launch_gemm_split(const GemmArgs &a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return hipSuccess;
+    if (a.ldw < gemm_padded_k(a.K) || !a.Wsplit) return hipErrorInvalidValue;
+    const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
+    const int grid = ((mt + 7) / 8) * 8 * nt;
+    hipLaunchKernelGGL(gemm_bf16x6_kernel, dim3(grid), dim3(256), 0, s, a, mt, nt);
+    return hipGetLastError();
+}
+
+}  // namespace uvad

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -21,6 +22,7 @@ struct HostTensor {
 
 struct LayerDev {
     float *w_ih = nullptr;   // [dirs*4H (permuted: dir, unit, gate)][in]
+    unsigned short *w_ih_split = nullptr;   // the same as three bf16 planes (gemm_split.hip)
     float *bias = nullptr;   // [dirs*4H] b_ih + b_hh, same permutation
     float *w_hh = nullptr;   // [dirs][packed register image]
     int in = 0;
@@ -39,6 +41,8 @@ struct uvad_ctx {
     int mel_stride = 0;
     std::vector<LayerDev> layers;
     std::vector<float *> lin_w, lin_b;
+    std::vector<unsigned short *> lin_w_split;
+    int gemm_mode = 1;   // 0: exact f32 MFMA (gemm.hip); 1: split-bf16 x6 (gemm_split.hip)
     float *cls_w = nullptr, *cls_b = nullptr;
     std::vector<void *> allocs;
     // timing
@@ -175,6 +179,7 @@ int uvad_create(int device, const uvad_fbank_cfg *fb, const uvad_model_cfg *mode
             return fail(c, UVAD_E_ARG, "bad model configuration");
     }
     for (auto &ev : c->ev) HIPCHK(c, hipEventCreate(&ev));
+    if (const char *e = std::getenv("UVAD_GEMM")) c->gemm_mode = std::strcmp(e, "f32") == 0 ? 0 : 1;
     return UVAD_OK;
 }
 
@@ -258,11 +263,17 @@ int uvad_finalize(uvad_ctx *c) {
         L.in = in;
         int r;
         if ((r = dev_upload(c, wp.data(), wp.size(), &L.w_ih))) return r;
+        {
+            std::vector<unsigned short> sp(3 * wp.size());
+            split_weights_bf16x3(wp.data(), wp.size(), sp.data());
+            if ((r = dev_upload(c, sp.data(), sp.size(), &L.w_ih_split))) return r;
+        }
         if ((r = dev_upload(c, bp.data(), bp.size(), &L.bias))) return r;
         if ((r = dev_upload(c, hh.data(), hh.size(), &L.w_hh))) return r;
     }
     c->lin_w.assign(m.lin_layers, nullptr);
     c->lin_b.assign(m.lin_layers, nullptr);
+    c->lin_w_split.assign(m.lin_layers, nullptr);
     int prev = H * D;
     for (int j = 0; j < m.lin_layers; ++j) {
         const HostTensor *w = get("linear." + std::to_string(j) + ".weight"), *b = get("linear." + std::to_string(j) + ".bias");
@@ -274,6 +285,11 @@ int uvad_finalize(uvad_ctx *c) {
         std::vector<float> wpad((size_t)m.lin_hidden * prevp, 0.0f);
         for (int o = 0; o < m.lin_hidden; ++o) std::memcpy(&wpad[(size_t)o * prevp], &w->data[(size_t)o * prev], sizeof(float) * prev);
         if ((r = dev_upload(c, wpad.data(), wpad.size(), &c->lin_w[j]))) return r;
+        {
+            std::vector<unsigned short> sp(3 * wpad.size());
+            split_weights_bf16x3(wpad.data(), wpad.size(), sp.data());
+            if ((r = dev_upload(c, sp.data(), sp.size(), &c->lin_w_split[j]))) return r;
+        }
         if ((r = dev_upload(c, b->data.data(), b->data.size(), &c->lin_b[j]))) return r;
         prev = m.lin_hidden;
     }
@@ -344,8 +360,9 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         g.B = B; g.T = T; g.act = 0; g.leaky_slope = 0.f;
         if (k == 0) { g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1; }
         else { g.A = Y[(k - 1) & 1]; g.lda = w.Wd; g.a_mode = 0; }
+        g.Wsplit = L.w_ih_split;
         if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k], s));
-        HIPCHK(c, launch_gemm(g, s));
+        HIPCHK(c, c->gemm_mode == 1 ? launch_gemm_split(g, s) : launch_gemm(g, s));
         if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k + 1], s));
         LstmArgs r{};
         r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.Y = Y[k & 1]; r.ldy = w.Wd;
@@ -360,8 +377,8 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         GemmArgs g{};
         g.A = cur; g.lda = curw; g.a_mode = 0; g.W = c->lin_w[j]; g.ldw = gemm_padded_k(curw); g.bias = c->lin_b[j]; g.C = Z[j & 1];
         g.M = (int)w.M; g.N = m.lin_hidden; g.K = curw; g.ldc = m.lin_hidden; g.B = B; g.T = T;
-        g.act = 1; g.leaky_slope = m.leaky_slope;
-        HIPCHK(c, launch_gemm(g, s));
+        g.act = 1; g.leaky_slope = m.leaky_slope; g.Wsplit = c->lin_w_split[j];
+        HIPCHK(c, c->gemm_mode == 1 ? launch_gemm_split(g, s) : launch_gemm(g, s));
         cur = Z[j & 1];
         curw = m.lin_hidden;
     }
@@ -436,6 +453,13 @@ int uvad_median_filter(uvad_ctx *c, const float *d_probs, int B, int T, int kern
     if (!c || !d_probs || !d_labels || B <= 0 || T <= 0) return UVAD_E_ARG;
     if (kernel < 1 || kernel % 2 == 0) return fail(c, UVAD_E_ARG, "median kernel must be odd");
     HIPCHK(c, launch_median(d_probs, B, T, kernel, d_labels, (hipStream_t)stream));
+    return UVAD_OK;
+}
+
+int uvad_set_gemm_mode(uvad_ctx *c, int mode) {
+    if (!c) return UVAD_E_ARG;
+    if (mode != 0 && mode != 1) return fail(c, UVAD_E_ARG, "gemm mode must be 0 (exact f32 MFMA) or 1 (split-bf16 x6)");
+    c->gemm_mode = mode;
     return UVAD_OK;
 }
 

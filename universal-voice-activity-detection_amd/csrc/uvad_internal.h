@@ -18,6 +18,7 @@ struct GemmArgs {
     const float *W;      // [N][ldw] row-major (torch Linear / LSTM weight layout, rows possibly permuted),
                          // each row zero-padded to ldw = gemm_padded_k(K) floats
     int ldw;
+    const unsigned short *Wsplit;   // gemm_split.hip only: the same matrix as three bf16 planes [3][N][ldw]
     const float *bias;   // [N] or nullptr
     float *C;
     int M, N, K;
@@ -31,6 +32,9 @@ struct GemmArgs {
 };
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t s);
 int gemm_padded_k(int K);   // K rounded up to the kernel's K-step
+// ---- gemm_split.hip: same contract on the bf16 matrix cores with 3-way split operands ("bf16x6") --
+hipError_t launch_gemm_split(const GemmArgs &a, hipStream_t s);
+void split_weights_bf16x3(const float *w, size_t n, unsigned short *out /*[3][n]*/);
 
 // ---- lstm.hip -----------------------------------------------------------------------------
 // One layer, all directions: grid (tiles, dirs).  G holds x_t*W_ih^T + b_ih + b_hh with column

@@ -168,6 +168,10 @@ class VadRuntime:
             self._check(self.lib.uvad_median_filter(self.ctx, probs.data_ptr(), B, T, int(kernel), out.data_ptr(), self._stream()))
             return out
 
+    def set_gemm_mode(self, mode: str):
+        """"f32": exact f32 MFMA; "bf16x6": split-bf16 on the bf16 matrix cores (default)."""
+        self._check(self.lib.uvad_set_gemm_mode(self.ctx, {"f32": 0, "bf16x6": 1}[mode]))
+
     def set_timing(self, on: bool):
         self._check(self.lib.uvad_set_timing(self.ctx, int(on)))
 
