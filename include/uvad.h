@@ -123,13 +123,20 @@ int uvad_get_taps(uvad_ctx *, int B, int T, float *d_lstm_out, float *d_lin_out,
                   const void *d_workspace, void *stream);
 
 /* Streaming (BASELINE cfg 5; the reference has no streaming mode): causal model
- * (bidirectional = 0), carried state.  d_state holds, per stream, the PCM tail needed by the next
- * frame and (h, c) of every layer; uvad_stream_state_bytes gives its size for B streams; zero it
- * to start a stream.  d_pcm_chunk [B][chunk] with chunk a multiple of frame_shift produces
- * chunk/frame_shift new logits per stream in d_logits [B][chunk/frame_shift]. */
+ * (bidirectional = 0) with carried state, B streams advancing in lockstep.  Semantics: the logits of
+ * frame t are EXACTLY those of the offline path (uvad_forward on the whole signal) because features use
+ * the same centred framing; a frame is emitted once its last sample (t*shift - (len-shift)/2 + len) has
+ * arrived, i.e. with a look-ahead of 280 samples at the reference geometry.  Each call consumes
+ * d_pcm_chunk [B][chunk] and writes the newly complete frames to d_logits [B][ld_logits] (row b, columns
+ * 0..k-1); the return value is k >= 0 (same for every stream) or a negative error.  d_state is caller-owned
+ * device memory of uvad_stream_state_bytes(ctx, B) bytes holding the PCM tail and (h, c) of every layer;
+ * uvad_stream_reset (re)starts all B streams.  The right-edge reflection of the offline path needs the end
+ * of the signal and is therefore never produced (streams are open-ended). */
 size_t uvad_stream_state_bytes(const uvad_ctx *, int B);
+size_t uvad_stream_workspace_bytes(const uvad_ctx *, int B, int chunk);
+int uvad_stream_reset(uvad_ctx *, void *d_state, int B, void *stream);
 int uvad_stream_step(uvad_ctx *, const float *d_pcm_chunk, int B, int chunk, void *d_state,
-                     float *d_logits, void *d_workspace, size_t ws_bytes, void *stream);
+                     float *d_logits, int ld_logits, void *d_workspace, size_t ws_bytes, void *stream);
 
 /* Replaces: median_filter (src/utils/helper.py:66-97) as used by VadModel.predict_step
  * (vad_engine.py:204-211): threshold 0.5 then odd `kernel`-tap median, zero padded edges.

@@ -234,3 +234,72 @@ def test_library_is_loaded_and_errors_are_loud():
         _lib.check(lib, rt.ctx, lib.uvad_classify(rt.ctx, torch.zeros(4, device=dev).data_ptr(), 1, 10, None, None,
                                                   torch.zeros(4, device=dev).data_ptr(), 16, None))
     assert ei.value.code == -4                 # workspace too small
+
+
+@pytest.mark.parametrize("chunk", [320, 160, 1600])
+def test_streaming_equals_offline_causal_model(chunk):
+    """BASELINE cfg 5 semantics: B lock-step streams fed `chunk` samples per step through uvad_stream_step give,
+    frame for frame, the logits of the offline path on the whole signal (causal model => identical by causality),
+    and match the reference's unidirectional PyanNet2 (golden pyannet2_uni) operator sequence in the oracle."""
+    import uvad_amd
+    from uvad_amd.synth import synth_pcm, seed_weights
+    from oracle import c_oracle as co
+    dev = torch.device("cuda:0")
+    B, S, F = 6, 16000 * 2, 64
+    pcm = synth_pcm(B, S, seed=77)
+    m = uvad_amd.PyanNet2(lstm={"bidirectional": False}, encoding_dim=F)
+    m.build()
+    seed_weights(m, 1234, 4.0)
+    m.attach_fbank(uvad_amd.FbankConfig(num_filters=F, window_type="povey"))
+    m = m.to(dev).eval()
+    rt = m.runtime(dev)
+    x = torch.from_numpy(pcm).to(dev)
+    offline, _ = rt.forward(x)
+    st = rt.stream_open(B, chunk)
+    outs = []
+    for i in range(S // chunk):
+        outs.append(rt.stream_step(st, x[:, i * chunk:(i + 1) * chunk].contiguous()).clone())
+    got = torch.cat(outs, dim=1)
+    n = got.shape[1]
+    T = S // 160
+    assert n == (S + 120 - 400) // 160 + 1      # every frame whose last sample has arrived
+    assert n >= T - 2
+    # Every emitted frame equals the offline logit up to fp32 rounding: the chunked feature kernel pairs
+    # frames differently inside its two-frames-per-FFT trick (1e-7 feature differences, amplified by the net).
+    sdiff = float((got - offline[:, :n]).abs().max())
+    print(f"streaming chunk={chunk}: {n} frames, max |stream - offline| = {sdiff:.2e}")
+    assert sdiff < LOGIT_TOL
+    # and the offline causal path itself against the oracle
+    cfg = co.default_fbank_cfg(F)
+    feats = co.fbank(pcm, cfg, co.window("povey", 400), co.mel_banks(cfg))
+    sd = {k: v.cpu().numpy() for k, v in m.state_dict().items()}
+    want, _ = co.classify(sd, co.ModelCfg(F, 128, 4, 0, 128, 2, 0.01), feats)
+    assert np.abs(offline.cpu().numpy() - want).max() < 5e-3
+    lg2, _ = m.forward_logits(torch.from_numpy(feats).to(dev))
+    assert np.abs(lg2.cpu().numpy() - want).max() < LOGIT_TOL
+
+
+def test_streaming_rejects_bidirectional_and_unreset_state():
+    import uvad_amd
+    from uvad_amd import _lib
+    dev = torch.device("cuda:0")
+    m = uvad_amd.PyanNet2(encoding_dim=64)
+    m.build()
+    m.attach_fbank(uvad_amd.FbankConfig(num_filters=64))
+    rt = m.to(dev).runtime(dev)
+    with pytest.raises(_lib.UvadError) as ei:
+        rt.stream_open(4, 320)
+    assert ei.value.code == -5
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x6"])
+def test_both_gemm_modes_meet_the_logit_bound(mode):
+    g, sd, case = load_golden("pyannet2_f64_T1000")
+    dev = torch.device("cuda:0")
+    m = _model(case, sd, dev)
+    rt = m.runtime(dev)
+    rt.set_gemm_mode(mode)
+    logits, _ = m.forward_logits(torch.from_numpy(g["feats"]).to(dev))
+    err = np.abs(logits.cpu().numpy() - g["logits"]).max()
+    print(f"gemm mode {mode}: logit err vs reference golden {err:.2e}")
+    assert err < LOGIT_TOL

@@ -48,7 +48,9 @@ SIGNATURES = {
                                C.c_void_p, C.c_size_t, C.c_void_p]),
     "uvad_get_taps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uvad_stream_state_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
-    "uvad_stream_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+    "uvad_stream_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "uvad_stream_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "uvad_stream_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "uvad_median_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "uvad_set_gemm_mode": (C.c_int, [C.c_void_p, C.c_int]),

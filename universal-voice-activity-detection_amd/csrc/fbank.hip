@@ -111,8 +111,9 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
     const int n_left = a.snip_edges ? 0 : (L - sh) / 2;
     const int64_t s0 = t0 * sh - n_left;
     const int need = (nfr - 1) * sh + L;
-    const void *xrow = I16 ? (const void *)(reinterpret_cast<const int16_t *>(a.pcm) + (size_t)b * a.S)
-                           : (const void *)(reinterpret_cast<const float *>(a.pcm) + (size_t)b * a.S);
+    const size_t rstride = a.row_stride ? (size_t)a.row_stride : (size_t)a.S;
+    const void *xrow = I16 ? (const void *)(reinterpret_cast<const int16_t *>(a.pcm) + (size_t)b * rstride)
+                           : (const void *)(reinterpret_cast<const float *>(a.pcm) + (size_t)b * rstride);
 
     // ---- stage the PCM tile (reflect at the utterance edges) --------------------------------
     for (int i = tid * 4; i < need; i += 256 * 4) {
@@ -287,10 +288,40 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
 
 }  // namespace
 
+__global__ __launch_bounds__(256) void stream_stage_kernel(const float *chunk_pcm, int B, int chunk, int tail, int n_left,
+                                                           int first_step, const float *tail_in, float *tail_out, float *staging) {
+    const int W = tail + chunk;
+    const long long n = (long long)B * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / W), p = (int)(i - (long long)b * W);
+        float v;
+        if (p >= tail) {
+            v = chunk_pcm[(size_t)b * chunk + (p - tail)];
+        } else if (first_step) {
+            const int idx = p - tail;   // absolute sample index in [-tail, 0): mirror (including the edge sample)
+            v = (-idx <= n_left && -idx - 1 < chunk) ? chunk_pcm[(size_t)b * chunk + (-idx - 1)] : 0.0f;
+        } else {
+            v = tail_in[(size_t)b * tail + p];
+        }
+        staging[i] = v;
+        if (p >= chunk) tail_out[(size_t)b * tail + (p - chunk)] = v;
+    }
+}
+
 size_t fbank_lds_bytes(const FbankArgs &a) {
     const size_t raw_pad = (size_t)((((FR_WG - 1) * a.frame_shift + a.frame_len) + 3) & ~3);
     const size_t melw_pad = (size_t)((a.tab.mel_stride * a.n_mels + 3) & ~3);
     return (raw_pad + melw_pad) * sizeof(float) + 4 * (size_t)(ZB_ELEMS + PB_ELEMS) * sizeof(float2);
+}
+
+hipError_t launch_stream_stage(const float *chunk_pcm, int B, int chunk, int tail, int n_left, int first_step,
+                               const float *tail_in, float *tail_out, float *staging, hipStream_t s) {
+    const long long n = (long long)B * (tail + chunk);
+    long long g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(stream_stage_kernel, dim3((int)g), dim3(256), 0, s, chunk_pcm, B, chunk, tail, n_left, first_step,
+                       tail_in, tail_out, staging);
+    return hipGetLastError();
 }
 
 hipError_t launch_fbank(const FbankArgs &a, hipStream_t s) {

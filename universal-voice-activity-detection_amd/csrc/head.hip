@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void classifier_kernel(ClsArgs a) {
         const int b = tile * SEQ_TILE + j;
         if (b < a.B) {
             const float logit = acc + a.b[0];
-            const size_t o = (size_t)b * a.T + t;
+            const size_t o = (size_t)b * a.ld_out + t;
             if (a.logits) a.logits[o] = logit;
             if (a.probs) a.probs[o] = 1.0f / (1.0f + __expf(-logit));
         }

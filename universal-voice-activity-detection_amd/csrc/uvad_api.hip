@@ -28,7 +28,11 @@ struct LayerDev {
     int in = 0;
 };
 
+struct StreamCounters { int64_t n_samples = 0, n_frames = 0, n_steps = 0; };
+struct StreamState { float *h = nullptr, *c = nullptr; size_t layer_stride = 0; };
+
 struct uvad_ctx {
+    std::map<void *, StreamCounters> streams;   // host mirror of the lock-step stream groups, keyed by d_state
     int device = 0;
     bool has_fb = false, has_model = false, finalized = false, tables_set = false;
     uvad_fbank_cfg fb{};
@@ -341,7 +345,8 @@ int uvad_fbank_i16(uvad_ctx *c, const int16_t *d_pcm, int B, int64_t S, float *d
 }
 
 static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float *d_logits, float *d_probs,
-                         void *ws, size_t ws_bytes, hipStream_t s, bool record_start) {
+                         void *ws, size_t ws_bytes, hipStream_t s, bool record_start,
+                         const StreamState *ss = nullptr, int ld_out = 0) {
     const uvad_model_cfg &m = c->mc;
     const WsLayout w = carve(c, B, T);
     if (ws_bytes < w.total) return fail(c, UVAD_E_WORKSPACE, "workspace too small: need " + std::to_string(w.total) + " bytes");
@@ -367,6 +372,10 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         LstmArgs r{};
         r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.Y = Y[k & 1]; r.ldy = w.Wd;
         r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D;
+        if (ss) {   // carried (h, c) of this layer, updated in place
+            r.h0 = r.hN = ss->h + (size_t)k * ss->layer_stride;
+            r.c0 = r.cN = ss->c + (size_t)k * ss->layer_stride;
+        }
         HIPCHK(c, launch_lstm(r, s));
     }
     if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * m.num_layers], s));
@@ -384,7 +393,7 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
     }
     ClsArgs q{};
     q.Z = cur; q.ldz = curw; q.K = curw; q.w = c->cls_w; q.b = c->cls_b; q.logits = d_logits; q.probs = d_probs;
-    q.tiles = w.tiles; q.T = T; q.B = B;
+    q.tiles = w.tiles; q.T = T; q.B = B; q.ld_out = ld_out > 0 ? ld_out : T;
     HIPCHK(c, launch_classifier(q, s));
     if (c->timing) {
         HIPCHK(c, hipEventRecord(c->ev[3], s));
@@ -438,15 +447,105 @@ int uvad_get_taps(uvad_ctx *c, int B, int T, float *d_lstm_out, float *d_lin_out
     return UVAD_OK;
 }
 
+// ---- streaming ---------------------------------------------------------------------------------
+// state layout (bytes, 256-aligned blocks): tail[2][B][frame_len] f32 (ping-pong) | per layer: h [Bpad][H], c [Bpad][H]
+extern "C++" {
+namespace {
+struct StreamLayout {
+    int tail = 0, Bpad = 0;
+    size_t off_tail[2] = {0, 0}, off_h = 0, off_c = 0, layer_stride = 0, total = 0;
+};
+StreamLayout stream_layout(const uvad_ctx *c, int B) {
+    StreamLayout L;
+    L.tail = c->fb.frame_len;
+    L.Bpad = (B + SEQ_TILE - 1) / SEQ_TILE * SEQ_TILE;
+    size_t o = 0;
+    for (int i = 0; i < 2; ++i) { L.off_tail[i] = o; o += align_up((size_t)B * L.tail * sizeof(float)); }
+    L.layer_stride = align_up((size_t)L.Bpad * c->mc.hidden * sizeof(float));
+    L.off_h = o; o += L.layer_stride * c->mc.num_layers;
+    L.off_c = o; o += L.layer_stride * c->mc.num_layers;
+    L.total = o;
+    return L;
+}
+int stream_max_frames(const uvad_ctx *c, int chunk) { return chunk / c->fb.frame_shift + 1; }
+}  // namespace
+}  // extern "C++"
+
 size_t uvad_stream_state_bytes(const uvad_ctx *c, int B) {
-    (void)c; (void)B;
-    return 0;
+    if (!c || !c->has_fb || !c->has_model || B <= 0) return 0;
+    return stream_layout(c, B).total;
 }
 
-int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, void *d_state, float *d_logits,
+size_t uvad_stream_workspace_bytes(const uvad_ctx *c, int B, int chunk) {
+    if (!c || !c->has_fb || !c->has_model || B <= 0 || chunk <= 0) return 0;
+    const size_t staging = align_up((size_t)B * (c->fb.frame_len + chunk) * sizeof(float));
+    return staging + carve(c, B, stream_max_frames(c, chunk)).total;
+}
+
+int uvad_stream_reset(uvad_ctx *c, void *d_state, int B, void *stream) {
+    if (!c || !d_state || B <= 0) return UVAD_E_ARG;
+    if (!c->has_fb || !c->has_model) return fail(c, UVAD_E_STATE, "streaming needs both a fbank and a model configuration");
+    if (c->mc.bidirectional) return fail(c, UVAD_E_UNSUPPORTED, "streaming needs a causal model (lstm.bidirectional = False)");
+    HIPCHK(c, hipMemsetAsync(d_state, 0, stream_layout(c, B).total, (hipStream_t)stream));
+    c->streams[d_state] = StreamCounters();
+    return UVAD_OK;
+}
+
+int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, void *d_state, float *d_logits, int ld_logits,
                      void *ws, size_t ws_bytes, void *stream) {
-    (void)d_pcm_chunk; (void)B; (void)chunk; (void)d_state; (void)d_logits; (void)ws; (void)ws_bytes; (void)stream;
-    return fail(c, UVAD_E_UNSUPPORTED, "uvad_stream_step: streaming is not implemented in this build");
+    if (!c) return UVAD_E_ARG;
+    if (!d_pcm_chunk || !d_state || !d_logits || !ws || B <= 0 || chunk <= 0) return fail(c, UVAD_E_ARG, "uvad_stream_step: bad argument");
+    if (!c->finalized || !c->has_fb || !c->tables_set) return fail(c, UVAD_E_STATE, "uvad_stream_step: context not ready (tables / weights)");
+    if (c->mc.bidirectional) return fail(c, UVAD_E_UNSUPPORTED, "streaming needs a causal model (lstm.bidirectional = False)");
+    if (c->fb.snip_edges) return fail(c, UVAD_E_UNSUPPORTED, "streaming implements the centred (snip_edges = 0) framing only");
+    if (c->fb.n_mels != c->mc.in_dim) return fail(c, UVAD_E_ARG, "n_mels != encoding_dim");
+    auto it = c->streams.find(d_state);
+    if (it == c->streams.end()) return fail(c, UVAD_E_STATE, "uvad_stream_step: call uvad_stream_reset on this state first");
+    StreamCounters &sc = it->second;
+    const int L = c->fb.frame_len, sh = c->fb.frame_shift, n_left = (L - sh) / 2;
+    if (sc.n_samples == 0 && chunk < n_left) return fail(c, UVAD_E_ARG, "first chunk must hold at least (frame_len - shift)/2 samples");
+    if (ws_bytes < uvad_stream_workspace_bytes(c, B, chunk)) return fail(c, UVAD_E_WORKSPACE, "stream workspace too small");
+    const StreamLayout S = stream_layout(c, B);
+    hipStream_t s = (hipStream_t)stream;
+    char *st = reinterpret_cast<char *>(d_state);
+    char *wsb = reinterpret_cast<char *>(ws);
+    float *staging = reinterpret_cast<float *>(wsb);
+    const size_t staging_bytes = align_up((size_t)B * (L + chunk) * sizeof(float));
+    const int par = (int)(sc.n_steps & 1);
+    HIPCHK(c, launch_stream_stage(d_pcm_chunk, B, chunk, S.tail, n_left, sc.n_samples == 0 ? 1 : 0,
+                                  reinterpret_cast<const float *>(st + S.off_tail[par]),
+                                  reinterpret_cast<float *>(st + S.off_tail[par ^ 1]), staging, s));
+    const int64_t n_prev = sc.n_samples, n = n_prev + chunk;
+    // frame t spans [t*sh - n_left, t*sh - n_left + L): complete once n >= t*sh - n_left + L
+    const int64_t f_hi = n + n_left - L >= 0 ? (n + n_left - L) / sh : -1;
+    const int k = (int)(f_hi - (sc.n_frames - 1));
+    sc.n_samples = n;
+    sc.n_steps += 1;
+    if (k <= 0) return 0;
+    if (k > ld_logits) return fail(c, UVAD_E_ARG, "ld_logits smaller than the number of new frames");
+    const int64_t t0 = sc.n_frames;
+    const int64_t o = t0 * sh - n_left - (n_prev - S.tail);   // offset of frame t0 inside a staging row (>= 0)
+    sc.n_frames += k;
+    void *cws = wsb + staging_bytes;
+    const WsLayout w = carve(c, B, k);
+    float *feats = reinterpret_cast<float *>(reinterpret_cast<char *>(cws) + w.off_feats);
+    FbankArgs fa{};
+    fa.pcm = staging + o; fa.pcm_is_i16 = 0; fa.B = B; fa.S = (int64_t)(S.tail + chunk) - o; fa.T = k;
+    fa.row_stride = S.tail + chunk;
+    fa.frame_len = L; fa.frame_shift = sh; fa.n_mels = c->fb.n_mels;
+    fa.preemph = c->fb.preemph; fa.log_floor = c->fb.log_floor; fa.remove_dc = c->fb.remove_dc; fa.snip_edges = 1;
+    fa.feats = feats;
+    fa.tab.window = c->d_window; fa.tab.mel_start = c->d_mel_start; fa.tab.mel_len = c->d_mel_len;
+    fa.tab.mel_w = c->d_mel_w; fa.tab.mel_stride = c->mel_stride; fa.tab.tw512 = c->d_tw512;
+    HIPCHK(c, launch_fbank(fa, s));
+    StreamState ss;
+    ss.h = reinterpret_cast<float *>(st + S.off_h); ss.c = reinterpret_cast<float *>(st + S.off_c);
+    ss.layer_stride = S.layer_stride / sizeof(float);
+    const bool timing = c->timing;
+    c->timing = false;
+    const int r = classify_impl(c, feats, B, k, d_logits, nullptr, cws, ws_bytes - staging_bytes, s, false, &ss, ld_logits);
+    c->timing = timing;
+    return r < 0 ? r : k;
 }
 
 int uvad_median_filter(uvad_ctx *c, const float *d_probs, int B, int T, int kernel, uint8_t *d_labels, void *stream) {

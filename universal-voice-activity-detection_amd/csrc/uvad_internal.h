@@ -61,6 +61,7 @@ struct ClsArgs {
     const float *w, *b;
     float *logits, *probs;   // either may be nullptr
     int tiles, T, B;
+    int ld_out;              // row stride of logits / probs (>= T)
 };
 hipError_t launch_classifier(const ClsArgs &a, hipStream_t s);
 // rows (tile-major) -> canonical [B][T][W] copy, for the parity taps
@@ -80,6 +81,7 @@ struct FbankTables {            // device pointers owned by the ctx
 struct FbankArgs {
     const void *pcm; int pcm_is_i16;
     int B; int64_t S; int64_t T;
+    int64_t row_stride;         // elements between rows of pcm (0 = S)
     int frame_len, frame_shift, n_mels;
     float preemph, log_floor; int remove_dc, snip_edges;
     float *feats;               // [B][T][n_mels]
@@ -87,5 +89,9 @@ struct FbankArgs {
 };
 hipError_t launch_fbank(const FbankArgs &a, hipStream_t s);
 size_t fbank_lds_bytes(const FbankArgs &a);
+// streaming: staging[b] = [tail (frame_len samples, reflection-filled on the first step) | chunk];
+// new tail = last `tail` samples of staging
+hipError_t launch_stream_stage(const float *chunk_pcm, int B, int chunk, int tail, int n_left, int first_step,
+                               const float *tail_in, float *tail_out, float *staging, hipStream_t s);
 
 }  // namespace uvad

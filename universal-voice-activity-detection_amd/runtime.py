@@ -168,6 +168,33 @@ class VadRuntime:
             self._check(self.lib.uvad_median_filter(self.ctx, probs.data_ptr(), B, T, int(kernel), out.data_ptr(), self._stream()))
             return out
 
+    # ------------------------------------------------------------------ streaming (BASELINE cfg 5)
+    def stream_open(self, B: int, chunk: int):
+        """Allocate and reset the carried state of B lock-step streams fed `chunk` samples per step."""
+        with torch.cuda.device(self.device):
+            nbytes = int(self.lib.uvad_stream_state_bytes(self.ctx, B))
+            if nbytes == 0:
+                raise RuntimeError("streaming needs a runtime built with both a FbankConfig and a model")
+            state = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            ws = torch.empty(int(self.lib.uvad_stream_workspace_bytes(self.ctx, B, chunk)), dtype=torch.uint8, device=self.device)
+            self._check(self.lib.uvad_stream_reset(self.ctx, state.data_ptr(), B, self._stream()))
+            kmax = chunk // self._fb_c.frame_shift + 1
+            return {"state": state, "ws": ws, "B": B, "chunk": chunk,
+                    "out": torch.empty((B, kmax), dtype=torch.float32, device=self.device)}
+
+    def stream_step(self, st, pcm_chunk: "torch.Tensor") -> "torch.Tensor":
+        """pcm_chunk (B, chunk) f32 on the GPU -> logits (B, k) of the k frames completed by this chunk."""
+        with torch.cuda.device(self.device):
+            pcm_chunk = self._dev_f32(pcm_chunk, "pcm_chunk")
+            if tuple(pcm_chunk.shape) != (st["B"], st["chunk"]):
+                raise ValueError(f"expected a ({st['B']}, {st['chunk']}) chunk, got {tuple(pcm_chunk.shape)}")
+            out = st["out"]
+            k = self.lib.uvad_stream_step(self.ctx, pcm_chunk.data_ptr(), st["B"], st["chunk"], st["state"].data_ptr(),
+                                          out.data_ptr(), out.shape[1], st["ws"].data_ptr(), st["ws"].numel(), self._stream())
+            if k < 0:
+                self._check(k)
+            return out[:, :k]
+
     def set_gemm_mode(self, mode: str):
         """"f32": exact f32 MFMA; "bf16x6": split-bf16 on the bf16 matrix cores (default)."""
         self._check(self.lib.uvad_set_gemm_mode(self.ctx, {"f32": 0, "bf16x6": 1}[mode]))
