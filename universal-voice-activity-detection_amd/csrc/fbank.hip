@@ -32,17 +32,29 @@ constexpr int ZB_ELEMS = 64 * ZB_LD;           // 576 complex >= 512
 constexpr int PB_ELEMS = 264;                  // 257 (powerA, powerB) pairs, padded
 
 __device__ __forceinline__ void wave_lds_fence() {
-    // order this wave's LDS traffic (hardware executes one wave's DS ops in order; this stops
-    // the compiler from moving them across the hand-off point)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // Hand-off through the wave's own LDS scratch.  The hardware executes one wave's DS operations in
+    // issue order, so a ds_read issued after a ds_write of the same wave sees the written data; all that
+    // is needed is that the COMPILER keeps that order.  (A release/acquire fence pair here, even at
+    // wavefront scope, made hipcc drain vmcnt(0) -- i.e. wait for the feature stores of the previous
+    // frame pair to reach memory -- at every hand-off.)
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
 }
 
+// Wave-wide sum as a wave-uniform value, on the VALU (DPP), not through the LDS crossbar: four
+// xor-style steps give every lane its 16-lane row total, two row broadcasts accumulate the rows into
+// lane 63, a readlane returns it.  (A ds_bpermute butterfly costs an LDS round trip per step.)
+#define UVAD_DPP_ADD(V, CTRL, ROW_MASK)                                                                   \
+    V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, ROW_MASK, 0xF, true))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    UVAD_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+    UVAD_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+    UVAD_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror
+    UVAD_DPP_ADD(v, 0x140, 0xF);   // row_mirror: every lane holds its row total
+    UVAD_DPP_ADD(v, 0x142, 0xA);   // row_bcast:15 into rows 1 and 3
+    UVAD_DPP_ADD(v, 0x143, 0xC);   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // forward 8-point DFT, in place: out[q] = sum_r in[r] * exp(-2*pi*i*r*q/8)
@@ -94,8 +106,26 @@ __device__ __forceinline__ float pcm_at(const void *row, int64_t i) {
     return reinterpret_cast<const float *>(row)[i];
 }
 
+#ifdef UVAD_FB_STAMP   // diagnostic build (tools/fbank_ablate.hip): cycle shares of the stages of one wave
+#define FB_STAMP(i)                                                                        \
+    {                                                                                      \
+        unsigned long long t_;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        fb_acc[i] += t_ - fb_prev;                                                         \
+        fb_prev = t_;                                                                      \
+    }
+#else
+#define FB_STAMP(i)
+#endif
+
 template <bool I16>
 __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *__restrict__ tw512) {
+#ifdef UVAD_FB_STAMP
+    unsigned long long fb_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fb_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(fb_prev)::"memory");
+#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = a.frame_len, sh = a.frame_shift, F = a.n_mels;
     const int raw_pad = (((FR_WG - 1) * sh + L) + 3) & ~3;
@@ -116,35 +146,50 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
                            : (const void *)(reinterpret_cast<const float *>(a.pcm) + (size_t)b * rstride);
 
     // ---- stage the PCM tile (reflect at the utterance edges) --------------------------------
-    for (int i = tid * 4; i < need; i += 256 * 4) {
-        const int64_t g = s0 + i;
-        bool fast = g >= 0 && g + 3 < a.S && i + 3 < need;
-        if (fast) {
-            if (I16) {
-                const int16_t *p = reinterpret_cast<const int16_t *>(xrow) + g;
-                fast = (reinterpret_cast<uintptr_t>(p) & 7) == 0;
-                if (fast) {
-                    const short4 v = *reinterpret_cast<const short4 *>(p);
-                    raw[i + 0] = (float)v.x * (1.0f / 32768.0f);
-                    raw[i + 1] = (float)v.y * (1.0f / 32768.0f);
-                    raw[i + 2] = (float)v.z * (1.0f / 32768.0f);
-                    raw[i + 3] = (float)v.w * (1.0f / 32768.0f);
+    // All loads of the tile are issued before the first LDS write (ST_IT chunks of 4 samples per
+    // thread in flight): a load -> wait -> store loop would pay the HBM latency once per chunk.
+    constexpr int ST_IT = 8;   // 8 * 1024 samples >= (FR_WG - 1) * 160 + 400 for the reference geometry
+    for (int base = 0; base < need; base += ST_IT * 1024) {
+        float4 v[ST_IT];
+#pragma unroll
+        for (int it = 0; it < ST_IT; ++it) {
+            const int i = base + it * 1024 + tid * 4;
+            const int64_t g = s0 + i;
+            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < need) {
+                bool fast = g >= 0 && g + 3 < a.S;
+                if (I16) {
+                    const int16_t *p = reinterpret_cast<const int16_t *>(xrow) + g;
+                    fast = fast && (reinterpret_cast<uintptr_t>(p) & 7) == 0;
+                    if (fast) {
+                        const short4 q = *reinterpret_cast<const short4 *>(p);
+                        v[it] = make_float4((float)q.x * (1.0f / 32768.0f), (float)q.y * (1.0f / 32768.0f),
+                                            (float)q.z * (1.0f / 32768.0f), (float)q.w * (1.0f / 32768.0f));
+                    }
+                } else {
+                    const float *p = reinterpret_cast<const float *>(xrow) + g;
+                    fast = fast && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+                    if (fast) v[it] = *reinterpret_cast<const float4 *>(p);
                 }
-            } else {
-                const float *p = reinterpret_cast<const float *>(xrow) + g;
-                fast = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
-                if (fast) *reinterpret_cast<float4 *>(raw + i) = *reinterpret_cast<const float4 *>(p);
+                if (!fast) {
+                    float e4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int64_t idx = g + e;
+                        if (idx < 0) idx = -idx - 1;
+                        if (idx >= a.S) idx = 2 * a.S - 1 - idx;
+                        if (idx < 0) idx = 0;
+                        if (idx >= a.S) idx = a.S - 1;
+                        e4[e] = pcm_at<I16>(xrow, idx);
+                    }
+                    v[it] = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                }
             }
         }
-        if (!fast) {
-            for (int e = 0; e < 4 && i + e < need; ++e) {
-                int64_t idx = g + e;
-                if (idx < 0) idx = -idx - 1;
-                if (idx >= a.S) idx = 2 * a.S - 1 - idx;
-                if (idx < 0) idx = 0;
-                if (idx >= a.S) idx = a.S - 1;
-                raw[i + e] = pcm_at<I16>(xrow, idx);
-            }
+#pragma unroll
+        for (int it = 0; it < ST_IT; ++it) {
+            const int i = base + it * 1024 + tid * 4;
+            if (i < need) *reinterpret_cast<float4 *>(raw + i) = v[it];   // raw is padded to a multiple of 4
         }
     }
     // mel weights transposed to [bin-in-band][filter] so lane m reads conflict-free
@@ -164,8 +209,22 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
         tw2[r] = tw512[(8 * (lane & 7) * r) & (NFFT - 1)];
     }
     const int nfilt_pass = (F + 63) / 64;
+    // band starts of this lane's filters (passes 0 and 1 cover n_mels <= 128): loaded ONCE per workgroup.
+    // Inside the frame loop a global load would also make hipcc drain vmcnt(0), i.e. wait for the feature
+    // stores of the previous frame pair, every pair.
+    const int mst0 = a.tab.mel_start[lane < F ? lane : F - 1];
+    int mst1 = a.tab.mel_start[lane + 64 < F ? lane + 64 : F - 1];
+    int mst0v = mst0;
+    // Retire every global load issued so far BEFORE the frame loop: a register that is still "in flight"
+    // at loop entry makes hipcc put s_waitcnt vmcnt(0) at its first use INSIDE the loop, where it then
+    // also waits for the feature stores of the previous frame pair on every iteration.
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        asm volatile("" : "+v"(win[r]), "+v"(tw1[r].x), "+v"(tw1[r].y), "+v"(tw2[r].x), "+v"(tw2[r].y));
+    asm volatile("" : "+v"(mst0v), "+v"(mst1));
     __syncthreads();
 
+    FB_STAMP(0)   // [0] tile staging + per-lane constants
     float2 *zb = wscr + (size_t)wave * (ZB_ELEMS + PB_ELEMS);
     float2 *pb = zb + ZB_ELEMS;
     const float inv_len = 1.0f / (float)L;
@@ -182,13 +241,17 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
         float suma = 0.f, sumb = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
+            // unconditional LDS reads (index clamped into the frame); samples past the frame are
+            // zeroed by a select for the mean and by the zero window tap for the spectrum
             const int n = lane + 64 * r;
             const bool in = n < L;
-            const int np = n > 0 ? n - 1 : 0;
-            re[r] = in ? xa[n] : 0.f;
-            pa[r] = in ? xa[np] : 0.f;
-            im[r] = in ? xb[n] : 0.f;
-            pbv[r] = in ? xb[np] : 0.f;
+            const int nc = in ? n : L - 1;
+            const int np = nc > 0 ? nc - 1 : 0;
+            const float va = xa[nc], vpa = xa[np], vb = xb[nc], vpb = xb[np];
+            re[r] = in ? va : 0.f;
+            pa[r] = vpa;
+            im[r] = in ? vb : 0.f;
+            pbv[r] = vpb;
             suma += re[r];
             sumb += im[r];
         }
@@ -203,6 +266,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
             im[r] = has_b ? ((im[r] - mub) - a.preemph * (pbv[r] - mub)) * win[r] : 0.f;
         }
 
+        FB_STAMP(1)   // [1] framing, DC, pre-emphasis, window
         // ---- pass 1: DFT over n1 (n = 64 n1 + p), twiddle W512^(p k1) ----------------------------
         dft8(re, im);
 #pragma unroll
@@ -223,6 +287,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
             const float2 v = zb[lane * ZB_LD + k];
             re[k] = v.x; im[k] = v.y;
         }
+        FB_STAMP(2)   // [2] pass 1 + transpose
         // ---- pass 2: lane (k1, b): DFT over a -> c, twiddle W64^(b c) -----------------------------
         dft8(re, im);
 #pragma unroll
@@ -243,6 +308,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
             const float2 v = zb[lane * ZB_LD + k];
             re[k] = v.x; im[k] = v.y;
         }
+        FB_STAMP(3)   // [3] pass 2 + transpose
         // ---- pass 3: lane (k1, c): DFT over b -> d; Z[k1 + 8c + 64d] -------------------------------
         dft8(re, im);
         wave_lds_fence();
@@ -252,6 +318,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
             for (int d = 0; d < 8; ++d) zb[lam + 64 * d] = make_float2(re[d], im[d]);
         }
         wave_lds_fence();
+        FB_STAMP(4)   // [4] pass 3 + spectrum to LDS
         // ---- split the two real spectra, power: A = (Z[k] + conj Z[N-k])/2, B = (Z[k] - conj Z[N-k])/(2i)
 #pragma unroll
         for (int d = 0; d < 5; ++d) {
@@ -265,25 +332,41 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
             }
         }
         wave_lds_fence();
+        FB_STAMP(5)   // [5] split + power
         // ---- mel band sums + log; lane = filter ----------------------------------------------------
+        // Uniform trip count (the longest band, zero-padded weights) and 4 bins per iteration keep 8 LDS
+        // reads in flight instead of one dependent read per bin; bins past a filter's band meet zero weights.
         for (int ps = 0; ps < nfilt_pass; ++ps) {
             const int m = lane + 64 * ps;
-            if (m < F) {
-                const int st = a.tab.mel_start[m], ln = a.tab.mel_len[m];
-                float ea = 0.f, eb = 0.f;
-                for (int i = 0; i < ln; ++i) {
-                    const float wv = melw[i * F + m];
-                    const float2 pv = pb[st + i];
+            const int mm = m < F ? m : F - 1;
+            const int st = ps == 0 ? mst0v : mst1;   // n_mels <= 128 (checked by uvad_create): no global load in this loop
+            float ea = 0.f, eb = 0.f;
+            for (int i0 = 0; i0 < a.tab.mel_stride; i0 += 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = i0 + e;
+                    const float wv = i < a.tab.mel_stride ? melw[i * F + mm] : 0.f;
+                    const int k = st + i < NFFT / 2 ? st + i : NFFT / 2;
+                    const float2 pv = pb[k];
                     ea = __builtin_fmaf(wv, pv.x, ea);
                     eb = __builtin_fmaf(wv, pv.y, eb);
                 }
+            }
+            if (m < F) {
                 float *o = a.feats + ((size_t)b * a.T + t0 + fa) * F + m;
-                o[0] = logf(fmaxf(ea, a.log_floor));
-                if (has_b) o[F] = logf(fmaxf(eb, a.log_floor));
+                o[0] = __logf(fmaxf(ea, a.log_floor));
+                if (has_b) o[F] = __logf(fmaxf(eb, a.log_floor));
             }
         }
         wave_lds_fence();
+        FB_STAMP(6)   // [6] mel + log + store
     }
+#ifdef UVAD_FB_STAMP
+    if (lane == 0 && blockIdx.x == 3 && blockIdx.y == 5) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.feats) + wave * 8;
+        for (int i = 0; i < 8; ++i) o[i] = fb_acc[i];
+    }
+#endif
 }
 
 }  // namespace

@@ -160,7 +160,7 @@ int uvad_create(int device, const uvad_fbank_cfg *fb, const uvad_model_cfg *mode
         c->fb = *fb;
         c->has_fb = true;
         if (fb->n_fft != 512) return fail(c, UVAD_E_UNSUPPORTED, "only n_fft = 512 is implemented");
-        if (fb->frame_len < 2 || fb->frame_len > 512 || fb->frame_shift < 1 || fb->n_mels < 1 || fb->n_mels > 1024)
+        if (fb->frame_len < 2 || fb->frame_len > 512 || fb->frame_shift < 1 || fb->n_mels < 1 || fb->n_mels > 128)
             return fail(c, UVAD_E_ARG, "bad fbank configuration");
         // forward-FFT twiddles (cos, -sin)(2 pi j / 512), computed in double
         std::vector<float> tw(2 * 512);
