@@ -16,6 +16,9 @@
 // Exact f32: the MFMA is a k-ordered fmaf chain (bit-exact f32).
 #include "uvad_internal.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace uvad {
 
 namespace {
@@ -308,6 +311,129 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Skewed variant (H = 128, 8 waves): the production kernel for the reference geometry.
+//
+// Same data layout, same arithmetic and the same per-wave MFMA chains as lstm_rec_kernel<128, 8>,
+// but each step is cut in two at k = H/2 and the two wave groups (G0 = waves 0-3 = units 0..63,
+// G1 = waves 4-7 = units 64..127; one wave of each group per SIMD) run HALF A STEP APART:
+//
+//      barrier #2t            barrier #2t+1            barrier #2t+2
+//   G0:  | B(t) + cell update(t)   |  A(t+1)                 |  B(t+1) + cell update ...
+//   G1:  | A(t)                    |  B(t) + cell update(t)  |  A(t+1)
+//
+// A(t) = the 64 MFMAs that consume h_{t-1} of G0's units, B(t) = the 64 that consume G1's.  In every
+// interval one wave of a SIMD runs a chain plus its (VALU, LDS) cell update while its partner runs a
+// bare chain, so the matrix pipe -- the bound of this kernel -- keeps issuing during the cell update
+// and the LDS hand-off instead of idling through them as it does when all waves move in lock step.
+// Every wave executes the same program; G1 simply passes one extra barrier before the loop (and G0 one
+// after it).  Double buffering of the h tile makes the half-step skew safe: h_t of a group is written
+// one full interval before anyone reads it and overwritten two steps later.
+template <int H>
+__global__ __launch_bounds__(512) void lstm_rec_skew_kernel(LstmArgs a) {
+    constexpr int HS = H + 4, NQ = H / 8;   // NQ float4 reads per half chain
+    static_assert(H == 128, "one 16-unit MFMA row block per wave, 8 waves");
+    __shared__ __attribute__((aligned(16))) float hbuf[2][SEQ_TILE][HS];
+
+    const int tile = blockIdx.x, dir = blockIdx.y;
+    const bool reverse = dir == 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2;
+    const int jb = lane & 3, blk = lane >> 2;
+
+    float w[H];
+    {
+        const float4 *wp = reinterpret_cast<const float4 *>(a.Whh_packed + (size_t)dir * 4 * H * H);
+#pragma unroll
+        for (int kq = 0; kq < H / 4; ++kq) {
+            const float4 v = wp[(size_t)(wave * (H / 4) + kq) * 64 + lane];
+            w[4 * kq + 0] = v.x; w[4 * kq + 1] = v.y; w[4 * kq + 2] = v.z; w[4 * kq + 3] = v.w;
+        }
+    }
+    const int seq = tile * SEQ_TILE + jb, nseq = a.tiles * SEQ_TILE;
+    const int unit = wave * 16 + blk;
+    const size_t so = ((size_t)dir * nseq + seq) * H + unit;
+    float c = a.c0 ? a.c0[so] : 0.0f;
+    float hlast = 0.0f;
+    hbuf[0][jb][unit] = a.h0 ? a.h0[so] : 0.0f;
+    __syncthreads();
+
+    const size_t row0 = (size_t)tile * a.T * SEQ_TILE + jb;
+    const float *gbase = a.G + (size_t)dir * 4 * H + unit * 4;
+    float *ybase = a.Y + (size_t)dir * H + unit;
+
+    f32x4 gq[PD];
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+        const int sp = p < a.T ? p : a.T - 1;
+        const int t = reverse ? a.T - 1 - sp : sp;
+        gq[p] = *reinterpret_cast<const f32x4 *>(gbase + (row0 + (size_t)t * SEQ_TILE) * a.ldg);
+    }
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // the half-step skew (wave-uniform branch)
+
+    for (int s0 = 0; s0 < a.T; s0 += PD) {
+#pragma unroll
+      for (int u = 0; u < PD; ++u) {
+        const int s = s0 + u;
+        if (s >= a.T) break;   // wave-uniform
+        const int t = reverse ? a.T - 1 - s : s;
+#pragma unroll
+        for (int k = 0; k < H; ++k) asm volatile("" : "+a"(w[k]));   // W_hh stays in AGPRs (constraint only)
+
+        const float *hb = &hbuf[s & 1][jb][0];
+        GateState S;
+        S.a0 = gq[u];
+        S.a1 = S.a2 = S.a3 = f32x4{0.f, 0.f, 0.f, 0.f};
+        float4 hv[NQ];
+        // ---- A(s): k in [0, H/2) -- h_{s-1} of group 0's units ------------------------------------
+#pragma unroll
+        for (int kq = 0; kq < NQ; ++kq) hv[kq] = *reinterpret_cast<const float4 *>(hb + 4 * kq);
+#pragma unroll
+        for (int kq = 0; kq < NQ; ++kq) {
+            S.a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * kq + 0], hv[kq].x, S.a0, 0, 0, 0);
+            S.a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * kq + 1], hv[kq].y, S.a1, 0, 0, 0);
+            S.a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * kq + 2], hv[kq].z, S.a2, 0, 0, 0);
+            S.a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * kq + 3], hv[kq].w, S.a3, 0, 0, 0);
+            if (kq == NQ / 2) {   // refill this ring slot with the gates of step min(s + PD, T - 1)
+                const int sp = s + PD < a.T ? s + PD : a.T - 1;
+                const int tp = reverse ? a.T - 1 - sp : sp;
+                gq[u] = *reinterpret_cast<const f32x4 *>(gbase + (row0 + (size_t)tp * SEQ_TILE) * a.ldg);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, NQ, 0);       // all NQ reads in flight, then the chain
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NQ, 0);
+        __syncthreads();                                            // barrier #2s (G0) / #2s+1 (G1)
+
+        // ---- B(s): k in [H/2, H) -- h_{s-1} of group 1's units; then this wave's cell update --------
+#pragma unroll
+        for (int kq = 0; kq < NQ; ++kq) hv[kq] = *reinterpret_cast<const float4 *>(hb + H / 2 + 4 * kq);
+        __builtin_amdgcn_s_setprio(1);   // this wave has the long interval: its MFMAs go first
+#pragma unroll
+        for (int kq = 0; kq < NQ; ++kq) {
+            S.a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[H / 2 + 4 * kq + 0], hv[kq].x, S.a0, 0, 0, 0);
+            S.a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[H / 2 + 4 * kq + 1], hv[kq].y, S.a1, 0, 0, 0);
+            S.a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[H / 2 + 4 * kq + 2], hv[kq].z, S.a2, 0, 0, 0);
+            S.a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[H / 2 + 4 * kq + 3], hv[kq].w, S.a3, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, NQ, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NQ, 1);
+        __builtin_amdgcn_s_setprio(0);
+        gate_stages_upto<GATE_STAGES - 1>(S, c);
+        hlast = S.h;
+        hbuf[(s + 1) & 1][jb][unit] = S.h;
+        ybase[(row0 + (size_t)t * SEQ_TILE) * a.ldy] = S.h;
+        __syncthreads();                                            // barrier #2s+1 (G0) / #2s+2 (G1)
+      }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // G0 balances the barrier count
+    if (a.hN) {
+        a.hN[so] = hlast;
+        a.cN[so] = c;
+    }
+}
+
 }  // namespace
 
 size_t whh_packed_elems(int H) { return (size_t)4 * H * H; }
@@ -330,7 +456,10 @@ void pack_whh(const float *w_hh, int H, float *out) {
 hipError_t launch_lstm(const LstmArgs &a, hipStream_t s) {
     if (a.tiles <= 0 || a.T <= 0) return hipSuccess;
     dim3 grid(a.tiles, a.dirs);
-    if (a.H == 128)
+    static const bool plain = [] { const char *e = std::getenv("UVAD_LSTM"); return e && std::strcmp(e, "plain") == 0; }();
+    if (a.H == 128 && !plain)
+        hipLaunchKernelGGL(lstm_rec_skew_kernel<128>, grid, dim3(512), 0, s, a);
+    else if (a.H == 128)
         hipLaunchKernelGGL((lstm_rec_kernel<128, 8>), grid, dim3(512), 0, s, a);
     else if (a.H == 64)
         hipLaunchKernelGGL((lstm_rec_kernel<64, 4>), grid, dim3(256), 0, s, a);
