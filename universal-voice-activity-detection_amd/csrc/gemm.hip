@@ -26,9 +26,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // Row m of A.  Rows past M (or padded sequences, b >= B) are clamped to row 0: every load in the
 // kernel is unconditional (no exec-masked branches in the K loop); what such rows produce is
 // either never stored (row >= M) or belongs to a padded sequence nobody reads.
-__device__ __forceinline__ const float *a_row_ptr(const GemmArgs &a, int m) {
-    if (m >= a.M) return a.A;
-    if (a.a_mode == 0) return a.A + (size_t)m * a.lda;
+__device__ __forceinline__ const float *a_row_ptr(const GemmArgs &a, int m, int r0, int rend) {
+    if (m >= rend) return a.A + (a.a_mode == 1 ? (size_t)0 : (size_t)r0 * a.lda);
+    if (a.a_mode != 1) return a.A + (size_t)m * a.lda;
     const int per_tile = a.T * SEQ_TILE;
     const int tile = m / per_tile, rem = m - tile * per_tile;
     const int t = rem / SEQ_TILE, j = rem - t * SEQ_TILE;
@@ -46,17 +46,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a, int mt, int n
     const int xcd = bid & 7, idx = bid >> 3;
     const int m_tile = (idx / nt) * 8 + xcd, n_tile = idx % nt;
     if (m_tile >= mt) return;
-    const int R0 = m_tile * BM, C0 = n_tile * BN;
+    int R0 = m_tile * BM, Rend = a.M;
+    if (a.a_mode == 2) {   // time window of the tile-major matrix (see GemmArgs)
+        const int nblk = (a.win_tc * SEQ_TILE + BM - 1) / BM;
+        const int tile = m_tile / nblk, blk = m_tile - tile * nblk;
+        R0 = (tile * a.T + a.win_t0) * SEQ_TILE + blk * BM;
+        Rend = (tile * a.T + a.win_t0 + a.win_tc) * SEQ_TILE;
+    }
+    const int C0 = n_tile * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
     // staging assignment: 8 float4 per 32-float row, 32 rows per pass, 4 passes per operand
     const int srow = tid >> 3, skq = tid & 7;
-    const float *ap0 = a_row_ptr(a, R0 + srow) + skq * 4;
-    const float *ap1 = a_row_ptr(a, R0 + srow + 32) + skq * 4;
-    const float *ap2 = a_row_ptr(a, R0 + srow + 64) + skq * 4;
-    const float *ap3 = a_row_ptr(a, R0 + srow + 96) + skq * 4;
+    const float *ap0 = a_row_ptr(a, R0 + srow, R0, Rend) + skq * 4;
+    const float *ap1 = a_row_ptr(a, R0 + srow + 32, R0, Rend) + skq * 4;
+    const float *ap2 = a_row_ptr(a, R0 + srow + 64, R0, Rend) + skq * 4;
+    const float *ap3 = a_row_ptr(a, R0 + srow + 96, R0, Rend) + skq * 4;
     // W rows are zero-padded to ldw >= nk*BK; rows past N are clamped to row 0 (never stored)
     const int n0 = C0 + srow;
     const float *bp0 = a.W + (size_t)(n0 < a.N ? n0 : 0) * a.ldw + skq * 4;
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a, int mt, int n
     }
 
     // epilogue: C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool full = R0 + BM <= a.M && C0 + BN <= a.N;   // block-uniform: interior tiles store unguarded
+    const bool full = R0 + BM <= Rend && C0 + BN <= a.N;   // block-uniform: interior tiles store unguarded
 #define UVAD_EPILOGUE(ACC, I, J)                                                                     \
     {                                                                                                \
         const int col = C0 + wc * 64 + (J) * 32 + fr;                                                \
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a, int mt, int n
         } else {                                                                                     \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
                 const int dr = (r & 3) + 8 * (r >> 2);                                               \
-                if (rbase + dr < a.M && col < a.N) crow[(size_t)dr * a.ldc] = v[r];                  \
+                if (rbase + dr < Rend && col < a.N) crow[(size_t)dr * a.ldc] = v[r];                  \
             }                                                                                        \
         }                                                                                            \
     }
@@ -167,7 +174,9 @@ int gemm_padded_k(int K) { return (K + BK - 1) / BK * BK; }
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     if (a.ldw < gemm_padded_k(a.K)) return hipErrorInvalidValue;
-    const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
+    const int mt = a.a_mode == 2 ? a.win_tiles * ((a.win_tc * SEQ_TILE + BM - 1) / BM) : (a.M + BM - 1) / BM;
+    const int nt = (a.N + BN - 1) / BN;
+    if (mt <= 0) return hipSuccess;
     const int grid = ((mt + 7) / 8) * 8 * nt;
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(grid), dim3(256), 0, s, a, mt, nt);
     return hipGetLastError();

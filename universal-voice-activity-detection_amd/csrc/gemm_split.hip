@@ -22,9 +22,9 @@ constexpr int BM = 128, BN = 128, BK = 32, LDH = 40;   // LDH: LDS row stride in
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
-__device__ __forceinline__ const float *a_row_ptr(const GemmArgs &a, int m) {
-    if (m >= a.M) return a.A;
-    if (a.a_mode == 0) return a.A + (size_t)m * a.lda;
+__device__ __forceinline__ const float *a_row_ptr(const GemmArgs &a, int m, int r0, int rend) {
+    if (m >= rend) return a.A + (a.a_mode == 1 ? (size_t)0 : (size_t)r0 * a.lda);
+    if (a.a_mode != 1) return a.A + (size_t)m * a.lda;
     const int per_tile = a.T * SEQ_TILE;
     const int tile = m / per_tile, rem = m - tile * per_tile;
     const int t = rem / SEQ_TILE, j = rem - t * SEQ_TILE;
@@ -61,17 +61,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmArgs a, int mt,
     const int xcd = bid & 7, idx = bid >> 3;
     const int m_tile = (idx / nt) * 8 + xcd, n_tile = idx % nt;
     if (m_tile >= mt) return;
-    const int R0 = m_tile * BM, C0 = n_tile * BN;
+    int R0 = m_tile * BM, Rend = a.M;
+    if (a.a_mode == 2) {   // time window of the tile-major matrix (see GemmArgs)
+        const int nblk = (a.win_tc * SEQ_TILE + BM - 1) / BM;
+        const int tile = m_tile / nblk, blk = m_tile - tile * nblk;
+        R0 = (tile * a.T + a.win_t0) * SEQ_TILE + blk * BM;
+        Rend = (tile * a.T + a.win_t0 + a.win_tc) * SEQ_TILE;
+    }
+    const int C0 = n_tile * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
     // A staging: 8 float4 per 32-float row, 32 rows per pass, 4 passes
     const int srow = tid >> 3, skq = tid & 7;
-    const float *ap0 = a_row_ptr(a, R0 + srow) + skq * 4;
-    const float *ap1 = a_row_ptr(a, R0 + srow + 32) + skq * 4;
-    const float *ap2 = a_row_ptr(a, R0 + srow + 64) + skq * 4;
-    const float *ap3 = a_row_ptr(a, R0 + srow + 96) + skq * 4;
+    const float *ap0 = a_row_ptr(a, R0 + srow, R0, Rend) + skq * 4;
+    const float *ap1 = a_row_ptr(a, R0 + srow + 32, R0, Rend) + skq * 4;
+    const float *ap2 = a_row_ptr(a, R0 + srow + 64, R0, Rend) + skq * 4;
+    const float *ap3 = a_row_ptr(a, R0 + srow + 96, R0, Rend) + skq * 4;
     // W staging (pre-split bf16 planes [3][N][ldw]): thread = (row, 16-element half)
     const int brow = tid >> 1, bhalf = tid & 1;
     const int nrow = C0 + brow < a.N ? C0 + brow : 0;
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmArgs a, int mt,
     }
 
     // epilogue: identical to gemm.hip (C/D map of the 32x32 MFMA is dtype-independent)
-    const bool full = R0 + BM <= a.M && C0 + BN <= a.N;
+    const bool full = R0 + BM <= Rend && C0 + BN <= a.N;
 #define UVAD_EPILOGUE(ACC, I, J)                                                                     \
     {                                                                                                \
         const int col = C0 + wc * 64 + (J) * 32 + fr;                                                \
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmArgs a, int mt,
         } else {                                                                                     \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
                 const int dr = (r & 3) + 8 * (r >> 2);                                               \
-                if (rbase + dr < a.M && col < a.N) crow[(size_t)dr * a.ldc] = v[r];                  \
+                if (rbase + dr < Rend && col < a.N) crow[(size_t)dr * a.ldc] = v[r];                  \
             }                                                                                        \
         }                                                                                            \
     }
@@ -218,7 +225,9 @@ void split_weights_bf16x3(const float *w, size_t n, unsigned short *out) {
 hipError_t launch_gemm_split(const GemmArgs &a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     if (a.ldw < gemm_padded_k(a.K) || !a.Wsplit) return hipErrorInvalidValue;
-    const int mt = (a.M + BM - 1) / BM, nt = (a.N + BN - 1) / BN;
+    const int mt = a.a_mode == 2 ? a.win_tiles * ((a.win_tc * SEQ_TILE + BM - 1) / BM) : (a.M + BM - 1) / BM;
+    const int nt = (a.N + BN - 1) / BN;
+    if (mt <= 0) return hipSuccess;
     const int grid = ((mt + 7) / 8) * 8 * nt;
     hipLaunchKernelGGL(gemm_bf16x6_kernel, dim3(grid), dim3(256), 0, s, a, mt, nt);
     return hipGetLastError();

@@ -102,7 +102,7 @@ __device__ __forceinline__ void gq_load(f32x4 &dst, const float *p) {
 #define UVAD_YSTORE(ptr, v) (*(ptr) = (v))
 #endif
 
-template <int H, int WAVES>
+template <int H, int WAVES, bool HAS_G2>
 __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
     constexpr int UW = H / WAVES;   // hidden units per wave
     constexpr int RB = UW / 16;     // 16-unit MFMA row blocks per wave
@@ -150,15 +150,21 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
     const float *gbase = a.G + (size_t)dir * 4 * H;
     float *ybase = a.Y + (size_t)dir * H;
 
-    f32x4 gq[PD][RB];
+    // steps [s_begin, s_end) of the recurrence (a chunk when the host overlaps the next layer's projection)
+    const int s_begin = a.s_begin, s_end = a.s_count > 0 ? a.s_begin + a.s_count : a.T;
+    const float *gbase2 = HAS_G2 ? a.G2 + (size_t)dir * 4 * H : nullptr;
+    f32x4 gq[PD][RB], gq2[HAS_G2 ? PD : 1][RB];
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
-        const int sp = p < a.T ? p : a.T - 1;
+        const int sp = s_begin + p < s_end ? s_begin + p : s_end - 1;
         const int t = reverse ? a.T - 1 - sp : sp;
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RB; ++rb) {
             gq_load(gq[p][rb], gbase + (row0 + (size_t)t * SEQ_TILE) * a.ldg + unit[rb] * 4);
+            if constexpr (HAS_G2) gq_load(gq2[p][rb], gbase2 + (row0 + (size_t)t * SEQ_TILE) * a.ldg + unit[rb] * 4);
+        }
     }
+
     float hlast[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) hlast[rb] = 0.0f;
@@ -181,11 +187,11 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
     // gates of step s + PD, so every load lands in the register it is consumed from PD steps later
     // (no register rotation => the compiler can wait with a counted vmcnt instead of vmcnt(0), and
     // the h stores of the last steps stay in flight).
-    for (int s0 = 0; s0 < a.T; s0 += PD) {
+    for (int s0 = s_begin; s0 < s_end; s0 += PD) {
 #pragma unroll
       for (int u = 0; u < PD; ++u) {
         const int s = s0 + u;
-        if (s >= a.T) break;   // wave-uniform
+        if (s >= s_end) break;   // wave-uniform
         const int t = reverse ? a.T - 1 - s : s;
         // Pin the resident weights in the accumulator half of the unified register file: MFMA reads
         // A operands straight from AGPRs, and VALU-addressable VGPRs stay free for h / gates.
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
             for (int k = 0; k < H; ++k) asm volatile("" : "+a"(w[rb][k]));
 
         // h_{t-1} of this lane's sequence, all H values (broadcast reads: 4 distinct addresses per wave)
-        const float *hb = &hbuf[s & 1][jb][0];
+        const float *hb = &hbuf[(s - s_begin) & 1][jb][0];
         // RB > 1: every row block re-uses the values, keep them all; RB == 1: stream them (the register
         // budget of a two-waves-per-SIMD workgroup is 256: 128 for W_hh, the rest for everything else)
         // With RB == 1 they are streamed through a ring of HR slots, refilled right after use, so that
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
         for (int kq = 0; kq < HR; ++kq) hv[kq] = *reinterpret_cast<const float4 *>(hb + 4 * kq);
 #endif
 
-        float *hn = &hbuf[(s + 1) & 1][jb][0];
+        float *hn = &hbuf[(s - s_begin + 1) & 1][jb][0];
         float *yrow = ybase + (row0 + (size_t)t * SEQ_TILE) * a.ldy;
         // Row blocks one after the other, each as 4 independent accumulation chains (k mod 4):
         // dependent MFMAs are 4 issues apart.  Everything that does not depend on the running chain
@@ -223,6 +229,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             S[rb].a0 = gq[u][rb];
+            if constexpr (HAS_G2) S[rb].a0 += gq2[u][rb];
             S[rb].a1 = S[rb].a2 = S[rb].a3 = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
@@ -245,11 +252,13 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
                 if (rb == 0 && kq == H / 8) {
                     // refill this ring slot with the gates of step min(s + PD, T - 1) (branch-free: a
                     // redundant re-load of the last row is harmless)
-                    const int sp = s + PD < a.T ? s + PD : a.T - 1;
+                    const int sp = s + PD < s_end ? s + PD : s_end - 1;
                     const int tp = reverse ? a.T - 1 - sp : sp;
 #pragma unroll
-                    for (int r2 = 0; r2 < RB; ++r2)
+                    for (int r2 = 0; r2 < RB; ++r2) {
                         gq_load(gq[u][r2], gbase + (row0 + (size_t)tp * SEQ_TILE) * a.ldg + unit[r2] * 4);
+                        if constexpr (HAS_G2) gq_load(gq2[u][r2], gbase2 + (row0 + (size_t)tp * SEQ_TILE) * a.ldg + unit[r2] * 4);
+                    }
                 }
                 if (rb > 0 && kq <= GATE_STAGES) __builtin_amdgcn_sched_barrier(0);   // pin: MFMA group | stage | MFMA group ...
                 if (rb > 0) {   // cell update of the previous row block, one stage per MFMA group
@@ -456,13 +465,17 @@ void pack_whh(const float *w_hh, int H, float *out) {
 hipError_t launch_lstm(const LstmArgs &a, hipStream_t s) {
     if (a.tiles <= 0 || a.T <= 0) return hipSuccess;
     dim3 grid(a.tiles, a.dirs);
-    static const bool plain = [] { const char *e = std::getenv("UVAD_LSTM"); return e && std::strcmp(e, "plain") == 0; }();
-    if (a.H == 128 && !plain)
+    static const bool plain = [] { const char *e = std::getenv("UVAD_LSTM"); return !(e && std::strcmp(e, "skew") == 0); }();   // UVAD_LSTM=skew selects the half-step variant (measured 2 % slower)
+    if (a.H == 128 && !plain && !a.G2 && a.s_count == 0)
         hipLaunchKernelGGL(lstm_rec_skew_kernel<128>, grid, dim3(512), 0, s, a);
+    else if (a.H == 128 && a.G2)
+        hipLaunchKernelGGL((lstm_rec_kernel<128, 8, true>), grid, dim3(512), 0, s, a);
     else if (a.H == 128)
-        hipLaunchKernelGGL((lstm_rec_kernel<128, 8>), grid, dim3(512), 0, s, a);
+        hipLaunchKernelGGL((lstm_rec_kernel<128, 8, false>), grid, dim3(512), 0, s, a);
+    else if (a.H == 64 && a.G2)
+        hipLaunchKernelGGL((lstm_rec_kernel<64, 4, true>), grid, dim3(256), 0, s, a);
     else if (a.H == 64)
-        hipLaunchKernelGGL((lstm_rec_kernel<64, 4>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((lstm_rec_kernel<64, 4, false>), grid, dim3(256), 0, s, a);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

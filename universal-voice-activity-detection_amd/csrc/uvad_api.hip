@@ -47,6 +47,10 @@ struct uvad_ctx {
     std::vector<float *> lin_w, lin_b;
     std::vector<unsigned short *> lin_w_split;
     int gemm_mode = 1;   // 0: exact f32 MFMA (gemm.hip); 1: split-bf16 x6 (gemm_split.hip)
+    // overlap of layer k+1's input projection with layer k's recurrence (side stream + events)
+    int overlap = 0;     // off by default: measured neutral with the on-the-fly split GEMM (profiles/README.md); UVAD_OVERLAP=1
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ovl_ev;
     float *cls_w = nullptr, *cls_b = nullptr;
     std::vector<void *> allocs;
     // timing
@@ -88,7 +92,12 @@ int dev_upload(uvad_ctx *c, const T *host, size_t n, T **out) {
 struct WsLayout {
     int tiles = 0, D = 0, Wd = 0;
     size_t M = 0;
-    size_t off_G = 0, off_Y[2] = {0, 0}, off_Z[2] = {0, 0}, off_feats = 0, total = 0;
+    // off_G[set][dir]: gate pre-activation buffers.  Classic path: only [0][0].  Overlapped path: layer k
+    // reads the partial sums of set k&1 (one per direction of the layer below) while the projections of
+    // layer k+1 are written into set (k+1)&1.
+    size_t off_G[2][2] = {{0, 0}, {0, 0}}, off_Y[2] = {0, 0}, off_Z[2] = {0, 0}, off_feats = 0, off_state[2] = {0, 0}, total = 0;
+    bool overlap = false;
+    int chunk = 0, n_chunks = 1;
 };
 WsLayout carve(const uvad_ctx *c, int B, int64_t T) {
     WsLayout w;
@@ -97,8 +106,19 @@ WsLayout carve(const uvad_ctx *c, int B, int64_t T) {
     w.D = m.bidirectional ? 2 : 1;
     w.Wd = m.hidden * w.D;
     w.M = (size_t)w.tiles * SEQ_TILE * (size_t)T;
+    // Overlap pays when the recurrence leaves CUs idle (one workgroup per 4 sequences and direction) and
+    // the sequence is long enough to cut into chunks whose projection tiles are whole (multiples of 32 frames).
+    w.overlap = c->overlap && m.num_layers >= 2 && T >= 256 && w.tiles * w.D <= 144;
+    if (w.overlap) {
+        static const int want_chunks = [] { const char *e = std::getenv("UVAD_OVL_CHUNKS"); const int v = e ? std::atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();
+        w.chunk = (int)(((T + want_chunks - 1) / want_chunks + 31) / 32 * 32);
+        w.n_chunks = (int)((T + w.chunk - 1) / w.chunk);
+    }
     size_t o = 0;
-    w.off_G = o; o += align_up(w.M * 4 * m.hidden * w.D * sizeof(float));
+    const size_t gbytes = align_up(w.M * 4 * m.hidden * w.D * sizeof(float));
+    for (int set = 0; set < (w.overlap ? 2 : 1); ++set)
+        for (int d = 0; d < (w.overlap ? w.D : 1); ++d) { w.off_G[set][d] = o; o += gbytes; }
+    for (int i = 0; i < 2; ++i) { w.off_state[i] = o; o += align_up((size_t)w.D * w.tiles * SEQ_TILE * m.hidden * sizeof(float)); }
     for (int i = 0; i < 2; ++i) { w.off_Y[i] = o; o += align_up(w.M * w.Wd * sizeof(float)); }
     for (int i = 0; i < 2; ++i) { w.off_Z[i] = o; o += align_up(w.M * (size_t)(m.lin_layers > 0 ? m.lin_hidden : 0) * sizeof(float)); }
     w.off_feats = o; o += align_up((size_t)B * T * (c->has_fb ? (size_t)c->fb.n_mels : (size_t)m.in_dim) * sizeof(float));
@@ -184,6 +204,7 @@ int uvad_create(int device, const uvad_fbank_cfg *fb, const uvad_model_cfg *mode
     }
     for (auto &ev : c->ev) HIPCHK(c, hipEventCreate(&ev));
     if (const char *e = std::getenv("UVAD_GEMM")) c->gemm_mode = std::strcmp(e, "f32") == 0 ? 0 : 1;
+    if (const char *e = std::getenv("UVAD_OVERLAP")) c->overlap = std::strcmp(e, "0") == 0 ? 0 : 1;
     return UVAD_OK;
 }
 
@@ -305,6 +326,9 @@ int uvad_finalize(uvad_ctx *c) {
     if ((r = dev_upload(c, cb->data.data(), cb->data.size(), &c->cls_b))) return r;
     c->layer_ev.resize((size_t)2 * m.num_layers + 2);
     for (auto &ev : c->layer_ev) HIPCHK(c, hipEventCreate(&ev));
+    if (!c->side) HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    c->ovl_ev.resize((size_t)m.num_layers * 9 + 2);
+    for (auto &ev : c->ovl_ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     c->finalized = true;
     return UVAD_OK;
 }
@@ -352,31 +376,93 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
     if (ws_bytes < w.total) return fail(c, UVAD_E_WORKSPACE, "workspace too small: need " + std::to_string(w.total) + " bytes");
     if (w.M > (size_t)0x7fffffff) return fail(c, UVAD_E_UNSUPPORTED, "B*T exceeds 2^31 rows; split the batch");
     char *base = reinterpret_cast<char *>(ws);
-    float *G = reinterpret_cast<float *>(base + w.off_G);
     float *Y[2] = {reinterpret_cast<float *>(base + w.off_Y[0]), reinterpret_cast<float *>(base + w.off_Y[1])};
     float *Z[2] = {reinterpret_cast<float *>(base + w.off_Z[0]), reinterpret_cast<float *>(base + w.off_Z[1])};
     const int H = m.hidden, D = w.D, N4 = 4 * H * D;
+    auto Gbuf = [&](int set, int d) { return reinterpret_cast<float *>(base + w.off_G[set][d]); };
+    auto run_gemm = [&](const GemmArgs &g, hipStream_t st) { return c->gemm_mode == 1 ? launch_gemm_split(g, st) : launch_gemm(g, st); };
     if (c->timing && record_start) HIPCHK(c, hipEventRecord(c->ev[0], s));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
-    for (int k = 0; k < m.num_layers; ++k) {
-        const LayerDev &L = c->layers[k];
-        GemmArgs g{};
-        g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.bias = L.bias; g.C = G; g.M = (int)w.M; g.N = N4; g.K = L.in; g.ldc = N4;
-        g.B = B; g.T = T; g.act = 0; g.leaky_slope = 0.f;
-        if (k == 0) { g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1; }
-        else { g.A = Y[(k - 1) & 1]; g.lda = w.Wd; g.a_mode = 0; }
-        g.Wsplit = L.w_ih_split;
-        if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k], s));
-        HIPCHK(c, c->gemm_mode == 1 ? launch_gemm_split(g, s) : launch_gemm(g, s));
-        if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k + 1], s));
-        LstmArgs r{};
-        r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.Y = Y[k & 1]; r.ldy = w.Wd;
-        r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D;
-        if (ss) {   // carried (h, c) of this layer, updated in place
-            r.h0 = r.hN = ss->h + (size_t)k * ss->layer_stride;
-            r.c0 = r.cN = ss->c + (size_t)k * ss->layer_stride;
+    const bool overlap = w.overlap && !ss;
+    if (!overlap) {
+        float *G = Gbuf(0, 0);
+        for (int k = 0; k < m.num_layers; ++k) {
+            const LayerDev &L = c->layers[k];
+            GemmArgs g{};
+            g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.Wsplit = L.w_ih_split; g.bias = L.bias; g.C = G;
+            g.M = (int)w.M; g.N = N4; g.K = L.in; g.ldc = N4; g.B = B; g.T = T; g.act = 0; g.leaky_slope = 0.f;
+            if (k == 0) { g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1; }
+            else { g.A = Y[(k - 1) & 1]; g.lda = w.Wd; g.a_mode = 0; }
+            if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k], s));
+            HIPCHK(c, run_gemm(g, s));
+            if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k + 1], s));
+            LstmArgs r{};
+            r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.Y = Y[k & 1]; r.ldy = w.Wd;
+            r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D;
+            if (ss) {   // carried (h, c) of this layer, updated in place
+                r.h0 = r.hN = ss->h + (size_t)k * ss->layer_stride;
+                r.c0 = r.cN = ss->c + (size_t)k * ss->layer_stride;
+            }
+            HIPCHK(c, launch_lstm(r, s));
         }
-        HIPCHK(c, launch_lstm(r, s));
+    } else {
+        // Layer k's recurrence runs in n_chunks launches on the caller's stream, carrying (h, c) through the
+        // workspace; as soon as a chunk is done, the projection of the frames it produced -- the forward
+        // direction's K-slice of layer k+1's W_ih over the forward chunk, the reverse direction's slice over
+        // the reverse chunk -- runs on the side stream, on the CUs the recurrence leaves idle.  Layer k+1
+        // then starts from the SUM of the per-direction partials (the recurrent kernel adds them).
+        const size_t need_ev = (size_t)m.num_layers * (w.n_chunks + 1) + 2;
+        if (c->ovl_ev.size() < need_ev) return fail(c, UVAD_E_STATE, "event pool too small for this sequence length");
+        size_t evi = 0;
+        float *hst = reinterpret_cast<float *>(base + w.off_state[0]), *cst = reinterpret_cast<float *>(base + w.off_state[1]);
+        {   // layer 0: one full projection of the features
+            const LayerDev &L = c->layers[0];
+            GemmArgs g{};
+            g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.Wsplit = L.w_ih_split; g.bias = L.bias; g.C = Gbuf(0, 0);
+            g.M = (int)w.M; g.N = N4; g.K = L.in; g.ldc = N4; g.B = B; g.T = T; g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1;
+            if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[0], s));
+            HIPCHK(c, run_gemm(g, s));
+            if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[1], s));
+        }
+        for (int k = 0; k < m.num_layers; ++k) {
+            const LayerDev &L = c->layers[k];
+            const int set = k & 1;
+            if (k > 0 && c->timing) {
+                HIPCHK(c, hipEventRecord(c->layer_ev[2 * k], s));
+                HIPCHK(c, hipEventRecord(c->layer_ev[2 * k + 1], s));
+            }
+            for (int ch = 0; ch < w.n_chunks; ++ch) {
+                const int sb = ch * w.chunk, sc = T - sb < w.chunk ? T - sb : w.chunk;
+                LstmArgs r{};
+                r.G = Gbuf(set, 0); r.G2 = (k > 0 && D == 2) ? Gbuf(set, 1) : nullptr; r.ldg = N4;
+                r.Whh_packed = L.w_hh; r.Y = Y[k & 1]; r.ldy = w.Wd;
+                r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D; r.s_begin = sb; r.s_count = sc;
+                r.h0 = ch == 0 ? nullptr : hst; r.c0 = ch == 0 ? nullptr : cst; r.hN = hst; r.cN = cst;
+                HIPCHK(c, launch_lstm(r, s));
+                if (k + 1 < m.num_layers) {
+                    hipEvent_t e = c->ovl_ev[evi++];
+                    HIPCHK(c, hipEventRecord(e, s));
+                    static const bool same = std::getenv("UVAD_OVL_SAMESTREAM") != nullptr;   // diagnostic: no concurrency
+                    hipStream_t gs = same ? s : c->side;
+                    HIPCHK(c, hipStreamWaitEvent(gs, e, 0));
+                    const LayerDev &Ln = c->layers[k + 1];
+                    for (int d = 0; d < D; ++d) {
+                        GemmArgs g{};
+                        g.A = Y[k & 1] + d * H; g.lda = w.Wd; g.a_mode = 2;
+                        g.W = Ln.w_ih + d * H; g.ldw = gemm_padded_k(Ln.in); g.Wsplit = Ln.w_ih_split + d * H;
+                        g.bias = d == 0 ? Ln.bias : nullptr; g.C = Gbuf(set ^ 1, d);
+                        g.M = (int)w.M; g.N = N4; g.K = H; g.ldc = N4; g.B = B; g.T = T;
+                        g.win_t0 = d == 0 ? sb : T - sb - sc; g.win_tc = sc; g.win_tiles = w.tiles;
+                        HIPCHK(c, run_gemm(g, gs));
+                    }
+                }
+            }
+            if (k + 1 < m.num_layers) {   // join: every partial of layer k+1 is complete
+                hipEvent_t e = c->ovl_ev[evi++];
+                HIPCHK(c, hipEventRecord(e, c->side));
+                HIPCHK(c, hipStreamWaitEvent(s, e, 0));
+            }
+        }
     }
     if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * m.num_layers], s));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
@@ -598,6 +684,9 @@ void uvad_destroy(uvad_ctx *c) {
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->layer_ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->ovl_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
 }
 

@@ -26,7 +26,13 @@ struct GemmArgs {
     // a_mode 0: row m of A is A + m*lda.
     // a_mode 1: A is canonical [B][T][K]; row m = (tile*T + t)*SEQ_TILE + j reads sequence
     //           b = tile*SEQ_TILE + j at frame t (zeros when b >= B).
+    //           (rows of padded sequences and rows past the tile's range are clamped, never stored)
+    // a_mode 2: "time window" of the tile-major matrix: the M-tiles cover, for every sequence tile, the
+    //           rows of frames [win_t0, win_t0 + win_tc): block i -> tile = i / nblk, rows starting at
+    //           (tile*T + win_t0)*SEQ_TILE + (i % nblk)*128; A and C use the same row index.  Used to
+    //           project the chunk of layer outputs a recurrent launch has just produced.
     int a_mode, B, T;
+    int win_t0, win_tc, win_tiles;
     float leaky_slope;   // act: v >= 0 ? v : slope*v when act == 1
     int act;
 };
@@ -41,9 +47,12 @@ void split_weights_bf16x3(const float *w, size_t n, unsigned short *out /*[3][n]
 // dir*4H + u*4 + gate; Y gets h_t at column dir*H + u.  Rows as above.
 struct LstmArgs {
     const float *G; int ldg;
+    const float *G2;             // optional second partial of the gate pre-activations (same layout), added to G
     const float *Whh_packed;     // per dir: register image, see pack_whh()
     float *Y; int ldy;
     int tiles, T, H, dirs;
+    int s_begin, s_count;        // steps [s_begin, s_begin + s_count) of the T-step recurrence (s_count 0 = all):
+                                 // forward visits t = s, reverse t = T-1-s; (h, c) carried through h0/c0 -> hN/cN
     // optional carried state (streaming): [dirs][tiles*SEQ_TILE][H], nullptr = zeros / discard
     const float *h0, *c0; float *hN, *cN;
 };
