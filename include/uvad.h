@@ -144,6 +144,12 @@ int uvad_stream_step(uvad_ctx *, const float *d_pcm_chunk, int B, int chunk, voi
 int uvad_median_filter(uvad_ctx *, const float *d_probs, int B, int T, int kernel, uint8_t *d_labels,
                        void *stream);
 
+/* Replaces: get_false_alarm / get_missed_detection (src/scripts/predict.py:666-673) on 0/1 frame rows:
+ * d_counts [B][2] uint32 = {#(gt == 0 and pred == 1), #(gt == 1 and pred == 0)} per row; the reference's
+ * FA / MD / DER are these counts divided by the row length (DER = FA + MD, vad_engine.py:102-105). */
+int uvad_der_counts(uvad_ctx *, const uint8_t *d_pred, const uint8_t *d_gt, int B, int T, uint32_t *d_counts,
+                    void *stream);
+
 /* Which kernel runs the time-parallel contractions (input projections, feed-forward layers):
  *   0  exact f32: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain, bit-compatible with f32 FMA arithmetic;
  *   1  (default) f32-accurate on the bf16 matrix cores: operands split exactly into three bf16 pieces,

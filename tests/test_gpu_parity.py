@@ -303,3 +303,19 @@ def test_both_gemm_modes_meet_the_logit_bound(mode):
     err = np.abs(logits.cpu().numpy() - g["logits"]).max()
     print(f"gemm mode {mode}: logit err vs reference golden {err:.2e}")
     assert err < LOGIT_TOL
+
+
+def test_detection_error_counts_match_numpy():
+    """predict.py:666-673 on the GPU: FA = #(gt==0 & pred==1)/N, MD = #(gt==1 & pred==0)/N, DER = FA + MD."""
+    import uvad_amd
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(9)
+    for B, T in [(5, 1000), (3, 37), (1, 16), (7, 3001)]:
+        pred = (rng.random((B, T)) < 0.4).astype(np.uint8)
+        gt = (rng.random((B, T)) < 0.5).astype(np.uint8)
+        out = uvad_amd.detection_error(torch.from_numpy(pred).to(dev), torch.from_numpy(gt).to(dev))
+        fa = ((gt == 0) & (pred == 1)).sum(1) / T
+        md = ((gt == 1) & (pred == 0)).sum(1) / T
+        assert np.allclose(out["false_alarm"].cpu().numpy(), fa, atol=0, rtol=1e-12)
+        assert np.allclose(out["missed_detection"].cpu().numpy(), md, atol=0, rtol=1e-12)
+        assert np.allclose(out["detection_error_rate"].cpu().numpy(), fa + md, atol=0, rtol=1e-12)

@@ -127,3 +127,19 @@ def test_synth_is_shard_invariant():
     full = synth_pcm(6, 8000, seed=1000)
     assert np.array_equal(full[4:6], synth_pcm(2, 8000, seed=1000, first=4))
     assert np.abs(full).max() <= 1.0 and full.std() > 0.05
+
+
+def test_interval_scoring_helpers_follow_the_reference():
+    # predict.py:614-634: buffer, clip to [0, duration], merge when the next start <= running end
+    assert uvad_amd.merge_intervals_with_buffer([(1, 2), (2.5, 3), (10, 11)], 12, 0.3) == [[0.7, 3.3], [9.7, 11.3]]
+    assert uvad_amd.merge_intervals_with_buffer([(0.1, 0.2)], 5, 0.5) == [[0, 0.7]]
+    assert uvad_amd.merge_intervals_with_buffer([(4, 4.9), (1, 2)], 5, 0.25) == [[0.75, 2.25], [3.75, 5]]
+    assert uvad_amd.merge_intervals_with_buffer([], 5, 0.5) == []
+    # predict.py:638-647: split long intervals into 10 s windows, drop remainders <= 0.1 s
+    assert uvad_amd.split_into_windows([[0, 25.05]]) == [[0, 10], [10, 20], [20, 25.05]]
+    assert uvad_amd.split_into_windows([[0, 20.05]]) == [[0, 10], [10, 20]]
+    assert uvad_amd.split_into_windows([[3, 3.05], [5, 6]]) == [[5, 6]]
+    # predict.py:654-663: ceil(duration/shift) frames, [int(s/shift), int(e/shift)) = 1
+    lab = uvad_amd.intervals_to_labels([(0.02, 0.05), (0.08, 0.2)], 0.1, 0.01)
+    assert lab.tolist() == [0, 0, 1, 1, 1, 0, 0, 0, 1, 1]
+    assert len(uvad_amd.intervals_to_labels([], 1.005, 0.01)) == 101

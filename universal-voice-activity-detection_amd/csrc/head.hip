@@ -82,7 +82,47 @@ __global__ __launch_bounds__(256) void median_kernel(const float *probs, int B, 
     labels[i] = ones > half ? 1 : 0;
 }
 
+// False-alarm / missed-detection frame counts per row (reference: get_false_alarm / get_missed_detection,
+// src/scripts/predict.py:666-673, applied to 0/1 frame tensors): one wave per row, 16 bytes per lane per
+// pass, wave-shuffle reduction.  counts[b] = {#(gt==0 & pred==1), #(gt==1 & pred==0)}.
+__global__ __launch_bounds__(256) void der_kernel(const uint8_t *pred, const uint8_t *gt, int B, int T, uint32_t *counts) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const uint8_t *p = pred + (size_t)b * T, *g = gt + (size_t)b * T;
+    unsigned fa = 0, md = 0;
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
+    int t = 0;
+    if (vec) {
+        for (t = lane * 16; t + 15 < T; t += 64 * 16) {
+            const uint4 pv = *reinterpret_cast<const uint4 *>(p + t), gv = *reinterpret_cast<const uint4 *>(g + t);
+            const unsigned pw[4] = {pv.x, pv.y, pv.z, pv.w}, gw[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {   // labels are 0/1 bytes: bit 0 of every byte
+                const unsigned pb = pw[i] & 0x01010101u, gb = gw[i] & 0x01010101u;
+                fa += __builtin_popcount(pb & ~gb);
+                md += __builtin_popcount(gb & ~pb);
+            }
+        }
+        t = T / 16 * 16;
+    }
+    for (int u = t + lane; u < T; u += 64) {
+        const unsigned pb = p[u] & 1u, gb = g[u] & 1u;
+        fa += pb & ~gb & 1u;
+        md += gb & ~pb & 1u;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { fa += __shfl_xor(fa, o); md += __shfl_xor(md, o); }
+    if (lane == 0) { counts[2 * b] = fa; counts[2 * b + 1] = md; }
+}
+
 }  // namespace
+
+hipError_t launch_der(const uint8_t *pred, const uint8_t *gt, int B, int T, uint32_t *counts, hipStream_t s) {
+    if (B <= 0 || T <= 0) return hipSuccess;
+    hipLaunchKernelGGL(der_kernel, dim3((B + 3) / 4), dim3(256), 0, s, pred, gt, B, T, counts);
+    return hipGetLastError();
+}
 
 hipError_t launch_classifier(const ClsArgs &a, hipStream_t s) {
     const long long rows = (long long)a.tiles * a.T * SEQ_TILE;

@@ -641,6 +641,12 @@ int uvad_median_filter(uvad_ctx *c, const float *d_probs, int B, int T, int kern
     return UVAD_OK;
 }
 
+int uvad_der_counts(uvad_ctx *c, const uint8_t *d_pred, const uint8_t *d_gt, int B, int T, uint32_t *d_counts, void *stream) {
+    if (!c || !d_pred || !d_gt || !d_counts || B <= 0 || T <= 0) return UVAD_E_ARG;
+    HIPCHK(c, launch_der(d_pred, d_gt, B, T, d_counts, (hipStream_t)stream));
+    return UVAD_OK;
+}
+
 int uvad_set_gemm_mode(uvad_ctx *c, int mode) {
     if (!c) return UVAD_E_ARG;
     if (mode != 0 && mode != 1) return fail(c, UVAD_E_ARG, "gemm mode must be 0 (exact f32 MFMA) or 1 (split-bf16 x6)");

@@ -54,3 +54,52 @@ def labels_to_intervals(labels, frame_shift: float) -> List[Tuple[float, float]]
         if e - s > 0.0:
             out.append((s, e))
     return out
+
+
+# ---- scoring side of get_new_cuts (src/scripts/predict.py:500-509, 612-673) -----------------------------------
+
+def merge_intervals_with_buffer(intervals, total_duration: float, buffer: float):
+    """predict.py:614-634: widen every interval by `buffer` (clipped to the recording) and merge overlaps."""
+    if len(intervals) == 0:
+        return []
+    iv = sorted(([max(s - buffer, 0), min(e + buffer, total_duration)] for s, e in intervals), key=lambda x: x[0])
+    out = [list(iv[0])]
+    for s, e in iv[1:]:
+        if s <= out[-1][1]:
+            out[-1][1] = e          # as the reference: the later interval's end replaces (not max) the running end
+        else:
+            out.append([s, e])
+    return out
+
+
+def split_into_windows(intervals, window: float = 10):
+    """predict.py:638-647: cut intervals longer than `window` seconds; drop remainders of 0.1 s or less."""
+    out = []
+    for s, e in intervals:
+        while e - s > window:
+            out.append([s, s + window])
+            s += window
+        if e - s > 0.1:
+            out.append([s, e])
+    return out
+
+
+def intervals_to_labels(intervals, total_duration: float, frame_shift: float) -> np.ndarray:
+    """predict.py:654-663 (get_binary_tensor): ceil(duration/shift) frames, [int(s/shift), int(e/shift)) set to 1."""
+    import math
+    lab = np.zeros(math.ceil(total_duration / frame_shift), np.uint8)
+    for s, e in intervals:
+        lab[int(s / frame_shift):int(e / frame_shift)] = 1
+    return lab
+
+
+def detection_error(pred_labels: torch.Tensor, gt_labels: torch.Tensor, runtime=None):
+    """(B, T) 0/1 predictions vs ground truth on the GPU -> dict of per-row FA, MD, DER fractions
+    (predict.py:666-673 / vad_engine.py:102-105).  The counting runs in uvad_der_counts."""
+    if not pred_labels.is_cuda:
+        raise RuntimeError("detection_error runs on the GPU only")
+    rt = runtime or _shared_runtime(pred_labels.device)
+    counts = rt.der_counts(pred_labels, gt_labels).to(torch.float64)
+    n = float(pred_labels.shape[1])
+    fa, md = counts[:, 0] / n, counts[:, 1] / n
+    return {"false_alarm": fa, "missed_detection": md, "detection_error_rate": fa + md}

@@ -199,6 +199,16 @@ class VadRuntime:
         """"f32": exact f32 MFMA; "bf16x6": split-bf16 on the bf16 matrix cores (default)."""
         self._check(self.lib.uvad_set_gemm_mode(self.ctx, {"f32": 0, "bf16x6": 1}[mode]))
 
+    def der_counts(self, pred: "torch.Tensor", gt: "torch.Tensor") -> "torch.Tensor":
+        """pred, gt (B, T) uint8 0/1 on the GPU -> (B, 2) int32 counts {false alarm, missed detection}."""
+        with torch.cuda.device(self.device):
+            pred = pred.to(torch.uint8).contiguous()
+            gt = gt.to(self.device, torch.uint8).contiguous()
+            B, T = pred.shape
+            out = torch.empty((B, 2), dtype=torch.int32, device=self.device)
+            self._check(self.lib.uvad_der_counts(self.ctx, pred.data_ptr(), gt.data_ptr(), B, T, out.data_ptr(), self._stream()))
+            return out
+
     def set_timing(self, on: bool):
         self._check(self.lib.uvad_set_timing(self.ctx, int(on)))
 
