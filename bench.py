@@ -120,9 +120,19 @@ def main():
     else:
         kern, flops_launch, dur_ms = "gemm_f32_kernel", frames_step * proj_f / L, ms["proj"] / L
     achieved = flops_launch / (dur_ms * 1e-3) / 1e12
+    # HBM bytes per launch of that kernel from the rocprofv3 PMC passes of this same workload (FETCH_SIZE doubled
+    # per MI355X_MICROARCH.md + WRITE_SIZE); bench.py cannot collect PMC counters itself, so the committed
+    # profile is quoted (null if absent or if the batch differs from the profiled one).
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "r01_v2_hbm_traffic.json")
+    if os.path.exists(tpath) and B == B_PER_GPU:
+        kk = json.load(open(tpath))["kernels"]
+        key = "lstm_rec_kernel" if kern.startswith("lstm") else next((k for k in kk if k.startswith("gemm") and "4096000" in k), None)
+        if key in kk:
+            traffic, traffic_src = kk[key]["hbm_MB_per_launch"] * 1e6, "profiles/r01_v2_hbm_traffic.json"
     roofline = {"kernel": kern, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": dur_ms,
-                "flops_per_launch": flops_launch}
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                "traffic_source": traffic_src, "avg_launch_ms": dur_ms, "flops_per_launch": flops_launch}
 
     out = {
         "metric": "audio frames/sec (log-mel + PyanNet2 VAD forward); per-frame logit max-abs-err vs CPU ref",
@@ -175,6 +185,7 @@ def cpu_baseline_and_error(model, rt, pcm, dev):
     gl_same, _ = rt.classify(feats_gpu, want_probs=False)
     ref_same = cpu(feats_gpu.cpu())[0]
     err_same = float((gl_same.cpu() - ref_same).abs().max())
+    err_same_mean = float((gl_same.cpu() - ref_same).abs().mean())
     # (2) end to end from PCM: adds the fp32-FFT difference between the two feature stages (~3e-5 in the
     #     log-mel domain), which the x4-scaled, near-chaotic test network amplifies ~200x.
     gl, _ = rt.forward(pcm[:nb].contiguous(), want_probs=False)
@@ -191,7 +202,7 @@ def cpu_baseline_and_error(model, rt, pcm, dev):
     return {"cpu_baseline": {"value": nb * T / dt, "unit": "frames/s", "cores": cores, "kind": "port",
                              "sample": f"first {nb} of the {x_all.shape[0]} utterances x 10 s, fbank + classifier, "
                                        f"torch {torch.__version__} CPU ops, {cores} threads, 1 rep ({dt:.1f} s)"},
-            "max_abs_logit_err": err_same,
+            "max_abs_logit_err": err_same, "mean_abs_logit_err": err_same_mean,
             "logit_err_sample": f"{nb} utterances x {T} frames, classifier on identical features vs torch-CPU reference path",
             "max_abs_logit_err_end_to_end": err_e2e, "max_abs_feature_err": feat_err,
             "logit_err_vs_f64_oracle": vs_oracle}
