@@ -319,3 +319,59 @@ def test_detection_error_counts_match_numpy():
         assert np.allclose(out["false_alarm"].cpu().numpy(), fa, atol=0, rtol=1e-12)
         assert np.allclose(out["missed_detection"].cpu().numpy(), md, atol=0, rtol=1e-12)
         assert np.allclose(out["detection_error_rate"].cpu().numpy(), fa + md, atol=0, rtol=1e-12)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(F=64, H=64, L=2, bi=True, lin_h=32, lin_l=1, B=5, T=37),      # 64-unit kernel (4 waves), odd batch, short T
+    dict(F=80, H=128, L=1, bi=False, lin_h=128, lin_l=0, B=1, T=1),    # single frame, no feed-forward, causal
+    dict(F=768, H=128, L=2, bi=True, lin_h=128, lin_l=2, B=3, T=50),   # SSL-feature width of the reference (encoding_dim=768)
+    dict(F=60, H=128, L=4, bi=True, lin_h=64, lin_l=3, B=9, T=5),      # K not a multiple of 32 (SincNet width), 3 FC layers
+    dict(F=64, H=128, L=4, bi=True, lin_h=128, lin_l=2, B=2, T=300),   # T >= 256 (chunk-capable length)
+])
+def test_model_variants_vs_oracle(cfg):
+    """Constructor variants the reference allows (PyanNet2.py:69-139) on seeded weights, against the C oracle
+    (the oracle itself is pinned to the reference class by the goldens for the default / uni / 1-layer shapes)."""
+    import uvad_amd
+    from uvad_amd.synth import seed_weights
+    from oracle import c_oracle as co
+    dev = torch.device("cuda:0")
+    m = uvad_amd.PyanNet2(lstm={"hidden_size": cfg["H"], "num_layers": cfg["L"], "bidirectional": cfg["bi"]},
+                          linear={"hidden_size": cfg["lin_h"], "num_layers": cfg["lin_l"]}, encoding_dim=cfg["F"])
+    m.build()
+    seed_weights(m, 77, 2.0)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(cfg["B"], cfg["T"], cfg["F"], generator=g) * 2.0 - 3.0
+    logits, probs = m.forward_logits(feats.to(dev))
+    sd = {k: v.cpu().numpy() for k, v in m.state_dict().items()}
+    mc = co.ModelCfg(cfg["F"], cfg["H"], cfg["L"], int(cfg["bi"]), cfg["lin_h"], cfg["lin_l"], 0.01)
+    want, wantp = co.classify(sd, mc, feats.numpy())
+    err = np.abs(logits.cpu().numpy() - want).max()
+    print(f"variant {cfg}: logit err {err:.2e}")
+    assert err < LOGIT_TOL
+    assert np.abs(probs.cpu().numpy() - wantp).max() < LOGIT_TOL
+
+
+def test_overlapped_projection_path_matches_classic():
+    """UVAD_OVERLAP=1 path (chunked recurrence + side-stream K-split projections) == classic path to rounding."""
+    import subprocess, sys, os
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        "sys.path.insert(0, os.getcwd())\n"
+        "import uvad_amd\n"
+        "from uvad_amd.synth import seed_weights\n"
+        "dev = torch.device('cuda:0')\n"
+        "m = uvad_amd.PyanNet2(encoding_dim=64); m.build(); seed_weights(m, 1234, 4.0); m = m.to(dev).eval()\n"
+        "g = torch.Generator().manual_seed(4321)\n"
+        "x = (torch.randn(6, 700, 64, generator=g) * 4 - 8).to(dev)\n"
+        "l, _ = m.forward_logits(x)\n"
+        "np.save(sys.argv[1], l.cpu().numpy())\n")
+    outs = []
+    for ov in ("0", "1"):
+        path = f"/tmp/uvad_ovl_{ov}.npy"
+        env = dict(os.environ, UVAD_OVERLAP=ov)
+        subprocess.check_call([sys.executable, "-c", code, path], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        outs.append(np.load(path))
+    d = np.abs(outs[0] - outs[1]).max()
+    print(f"overlap on vs off: max diff {d:.2e}")
+    assert d < LOGIT_TOL
