@@ -28,6 +28,10 @@ def _worker(rank, world, port, n_total, q):
     # each rank regenerates exactly its utterances; "result" = a per-utterance statistic over 3 frames
     local = torch.from_numpy(np.stack([np.abs(synth_pcm(1, 480, seed=1000, first=i)[0]).reshape(3, 160).mean(1) for i in idx])) \
         if idx else torch.zeros(0, 3)
+    # root-resident mode: scatter from rank 0 must hand every rank exactly the rows it would have generated
+    root = torch.from_numpy(np.stack([np.abs(synth_pcm(1, 480, seed=1000, first=i)[0]).reshape(3, 160).mean(1) for i in range(n_total)])) if r == 0 else None
+    got = udist.scatter_rows(root, n_total, r, w, like=torch.zeros(1, 3, dtype=torch.float32))
+    assert got.shape[0] == len(idx) and (len(idx) == 0 or torch.equal(got.to(local.dtype), local))
     full = udist.gather_rows(local, n_total, r, w)
     t = udist.max_over_ranks(float(r + 1))
     udist.barrier()

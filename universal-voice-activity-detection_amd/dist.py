@@ -58,6 +58,30 @@ def gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int) -> Opt
     return out
 
 
+def scatter_rows(full: Optional[torch.Tensor], n_total: int, rank: int, world: int, like: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Root-resident corpus mode: rank 0 holds ``full`` (n_total, ...) and every rank receives the
+    rows of ``shard_indices`` -- one RCCL scatter (root egress over all xGMI links at once; gloo in the CPU tests).
+    ``like`` gives non-root ranks the trailing shape / dtype / device.  Shards are padded to equal length."""
+    if world == 1:
+        return full
+    per = (n_total + world - 1) // world
+    ref = full if rank == 0 else like
+    if ref is None:
+        raise ValueError("non-root ranks must pass `like` (a tensor with the row shape, dtype and device)")
+    tail = tuple(ref.shape[1:])
+    recv = torch.empty((per,) + tail, dtype=ref.dtype, device=ref.device)
+    chunks = None
+    if rank == 0:
+        chunks = []
+        for r in range(world):
+            idx = shard_indices(n_total, r, world)
+            c = torch.zeros((per,) + tail, dtype=full.dtype, device=full.device)
+            c[: len(idx)] = full[idx]
+            chunks.append(c)
+    dist.scatter(recv, chunks, src=0)
+    return recv[: shard_count(n_total, rank, world)]
+
+
 def max_over_ranks(value: float, device=None) -> float:
     if not (dist.is_available() and dist.is_initialized()):
         return value
