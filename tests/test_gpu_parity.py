@@ -375,3 +375,37 @@ def test_overlapped_projection_path_matches_classic():
     d = np.abs(outs[0] - outs[1]).max()
     print(f"overlap on vs off: max diff {d:.2e}")
     assert d < LOGIT_TOL
+
+
+def test_tile16_throughput_kernel_matches_tile4():
+    """The 16-sequence recurrent kernel (auto-selected for >= 512 tile-directions; forced here with
+    UVAD_LSTM=tile16) against the 4-sequence kernel and the reference golden, incl. a partial last workgroup."""
+    import subprocess, sys, os
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        "sys.path.insert(0, os.getcwd())\n"
+        "sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))\n"
+        "import uvad_amd\n"
+        "from conftest import load_golden\n"
+        "g, sd, case = load_golden('pyannet2_f64_T1000')\n"
+        "dev = torch.device('cuda:0')\n"
+        "m = uvad_amd.PyanNet2(encoding_dim=64); m.build(); m.load_state_dict(sd); m = m.to(dev).eval()\n"
+        "x = torch.from_numpy(g['feats']).to(dev)\n"
+        "gen = torch.Generator().manual_seed(1)\n"
+        "extra = (torch.randn(19, 1000, 64, generator=gen) * 4 - 8).to(dev)\n"     # 21 sequences: 6 tiles -> 2 workgroups of 16, second partial
+        "l, _ = m.forward_logits(torch.cat([x, extra]))\n"
+        "np.save(sys.argv[1], l.cpu().numpy())\n"
+        "print('golden err', float(np.abs(l[:2].cpu().numpy() - g['logits']).max()))\n")
+    outs = []
+    for mode in ("tile4", "tile16"):
+        path = f"/tmp/uvad_lstm_{mode}.npy"
+        env = dict(os.environ, UVAD_LSTM=mode)
+        out = subprocess.check_output([sys.executable, "-c", code, path], env=env, text=True,
+                                      cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        err = float(out.strip().split()[-1])
+        print(f"{mode}: logit err vs reference golden {err:.2e}")
+        assert err < LOGIT_TOL
+        outs.append(np.load(path))
+    d = np.abs(outs[0] - outs[1]).max()
+    print(f"tile16 vs tile4: max diff {d:.2e}")
+    assert d < LOGIT_TOL

@@ -443,6 +443,123 @@ __global__ __launch_bounds__(512) void lstm_rec_skew_kernel(LstmArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Throughput variant for large batches (H = 128): 16 sequences per workgroup on v_mfma_f32_16x16x4_f32.
+//
+// When tiles*dirs exceeds the CU count the recurrence is no longer latency- but throughput-bound, and
+// the 2-pass 4x4x1 MFMA is the wrong instruction: it holds the vector issue port for its whole 8
+// cycles, so the cell updates are serialised behind the chains.  The 16x16x4 form does
+// the same MACs per cycle but issues once per 32 cycles, leaving 24 issue slots per MFMA to the VALU /
+// LDS work of both waves of the SIMD.  It needs N = 16 columns = 16 sequences per workgroup:
+//   A (16 rows x 4 k)  = W_hh rows of 4 units x 4 gates,   k-step ks covers k = 32*kk + ks (kk = lane>>4)
+//   B (4 k x 16 seqs)  = h_{t-1},  D: lane (q = lane>>4, j = lane&15) holds gates i,f,g,o (regs 0..3) of unit
+//   16*wave + 4*rb + q for sequence j  -> the cell update is lane-local again.
+// 8 waves x (4 row blocks x 32 k-steps) = 1024 MFMAs of 32 cycles per step and workgroup; W_hh stays in 128
+// AGPRs per lane.  Rows keep the SEQ_TILE = 4 layout (a workgroup owns 4 consecutive tiles), so GEMMs and
+// the classifier are unchanged.  No state carry / chunking (the callers that need those run small batches).
+template <int H>
+__global__ __launch_bounds__(512) void lstm_rec16_kernel(LstmArgs a) {
+    static_assert(H == 128, "written for H = 128");
+    constexpr int NS = 16, RB = 4, KS = H / 4, HSK = 36, PD16 = 2;
+    __shared__ __attribute__((aligned(16))) float hbuf[2][4][NS][HSK];   // [buffer][kk][sequence][32 (+4 pad)]
+
+    const int tile16 = blockIdx.x, dir = blockIdx.y;
+    const bool reverse = dir == 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, q = lane >> 4;
+
+    float w[RB * KS];
+    {
+        const float4 *wp = reinterpret_cast<const float4 *>(a.Whh_packed16 + (size_t)dir * 4 * H * H);
+#pragma unroll
+        for (int i = 0; i < RB * KS / 4; ++i) {
+            const float4 v = wp[(size_t)(wave * (RB * KS / 4) + i) * 64 + lane];
+            w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+    }
+    // this lane's sequence: tile (of 4) and row offset; lanes of missing tiles in the last workgroup are clamped
+    // for loads and masked for stores
+    const int t4 = tile16 * 4 + (j >> 2);
+    const bool live = t4 < a.tiles;
+    const int t4c = live ? t4 : a.tiles - 1;
+    const size_t row0 = (size_t)t4c * a.T * SEQ_TILE + (j & 3);
+    const int ubase = wave * 16 + q;   // unit of row block rb: ubase + 4*rb
+    const float *gbase = a.G + (size_t)dir * 4 * H + (size_t)ubase * 4;
+    float *ybase = a.Y + (size_t)dir * H + ubase;
+
+    float c[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        c[rb] = 0.0f;
+        const int u = ubase + 4 * rb;
+        hbuf[0][u >> 5][j][u & 31] = 0.0f;
+    }
+    __syncthreads();
+
+    f32x4 gq[PD16][RB];
+#pragma unroll
+    for (int p = 0; p < PD16; ++p) {
+        const int sp = p < a.T ? p : a.T - 1;
+        const int t = reverse ? a.T - 1 - sp : sp;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            gq[p][rb] = *reinterpret_cast<const f32x4 *>(gbase + (row0 + (size_t)t * SEQ_TILE) * a.ldg + 16 * rb);
+    }
+
+    for (int s0 = 0; s0 < a.T; s0 += PD16) {
+#pragma unroll
+      for (int u2 = 0; u2 < PD16; ++u2) {
+        const int s = s0 + u2;
+        if (s >= a.T) break;   // wave-uniform
+        const int t = reverse ? a.T - 1 - s : s;
+#pragma unroll
+        for (int k = 0; k < RB * KS; ++k) asm volatile("" : "+a"(w[k]));   // W_hh stays in AGPRs (constraint only)
+
+        // B operands: h_{s-1}[seq j][32*q + ks], ks = 0..31, as 8 x 16-byte reads
+        float4 hv[KS / 4];
+        const float *hb = &hbuf[s & 1][q][j][0];
+#pragma unroll
+        for (int i = 0; i < KS / 4; ++i) hv[i] = *reinterpret_cast<const float4 *>(hb + 4 * i);
+
+        f32x4 acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = gq[u2][rb];
+        {   // refill this ring slot with the gates of step min(s + PD16, T - 1)
+            const int sp = s + PD16 < a.T ? s + PD16 : a.T - 1;
+            const int tp = reverse ? a.T - 1 - sp : sp;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                gq[u2][rb] = *reinterpret_cast<const f32x4 *>(gbase + (row0 + (size_t)tp * SEQ_TILE) * a.ldg + 16 * rb);
+        }
+#pragma unroll
+        for (int i = 0; i < KS / 4; ++i) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[rb * KS + 4 * i + 0], hv[i].x, acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[rb * KS + 4 * i + 1], hv[i].y, acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[rb * KS + 4 * i + 2], hv[i].z, acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[rb * KS + 4 * i + 3], hv[i].w, acc[rb], 0, 0, 0);
+        }
+        float *yrow = ybase + (row0 + (size_t)t * SEQ_TILE) * a.ldy;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            GateState S;
+            S.a0 = acc[rb];
+            S.a1 = S.a2 = S.a3 = f32x4{0.f, 0.f, 0.f, 0.f};
+            gate_stages_upto<GATE_STAGES - 1>(S, c[rb]);
+            const int u = ubase + 4 * rb;
+            hbuf[(s + 1) & 1][u >> 5][j][u & 31] = S.h;
+            if (live) yrow[4 * rb] = S.h;
+        }
+        __syncthreads();
+      }
+    }
+}
+
 }  // namespace
 
 size_t whh_packed_elems(int H) { return (size_t)4 * H * H; }
@@ -462,9 +579,31 @@ void pack_whh(const float *w_hh, int H, float *out) {
                     }
 }
 
+// register image of lstm_rec16_kernel: [wave 8][rb 4][ks 32 (as 8 float4)][lane 64]
+void pack_whh16(const float *w_hh, int H, float *out) {
+    const int KS = H / 4;
+    for (int wave = 0; wave < 8; ++wave)
+        for (int rb = 0; rb < 4; ++rb)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 15, kk = lane >> 4;
+                    const int gate = i & 3, unit = wave * 16 + 4 * rb + (i >> 2);
+                    const int idx = rb * KS + ks;   // element index in the lane's w[] array
+                    out[((size_t)(wave * (4 * KS / 4) + idx / 4) * 64 + lane) * 4 + (idx & 3)] =
+                        w_hh[(size_t)(gate * H + unit) * H + 32 * kk + ks];
+                }
+}
+
 hipError_t launch_lstm(const LstmArgs &a, hipStream_t s) {
     if (a.tiles <= 0 || a.T <= 0) return hipSuccess;
     dim3 grid(a.tiles, a.dirs);
+    // large batches: 16 sequences per workgroup (throughput variant); UVAD_LSTM=tile16 / tile4 force either
+    static const int force16 = [] { const char *e = std::getenv("UVAD_LSTM"); return !e ? 0 : std::strcmp(e, "tile16") == 0 ? 1 : std::strcmp(e, "tile4") == 0 ? -1 : 0; }();
+    const bool can16 = a.H == 128 && a.Whh_packed16 && !a.G2 && a.s_count == 0 && !a.h0 && !a.hN;
+    if (can16 && (force16 > 0 || (force16 == 0 && a.tiles * a.dirs >= 512))) {
+        hipLaunchKernelGGL(lstm_rec16_kernel<128>, dim3((a.tiles + 3) / 4, a.dirs), dim3(512), 0, s, a);
+        return hipGetLastError();
+    }
     static const bool plain = [] { const char *e = std::getenv("UVAD_LSTM"); return !(e && std::strcmp(e, "skew") == 0); }();   // UVAD_LSTM=skew selects the half-step variant (measured 2 % slower)
     if (a.H == 128 && !plain && !a.G2 && a.s_count == 0)
         hipLaunchKernelGGL(lstm_rec_skew_kernel<128>, grid, dim3(512), 0, s, a);

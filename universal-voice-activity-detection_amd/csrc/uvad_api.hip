@@ -25,6 +25,7 @@ struct LayerDev {
     unsigned short *w_ih_split = nullptr;   // the same as three bf16 planes (gemm_split.hip)
     float *bias = nullptr;   // [dirs*4H] b_ih + b_hh, same permutation
     float *w_hh = nullptr;   // [dirs][packed register image]
+    float *w_hh16 = nullptr; // [dirs][register image of the 16-sequence kernel] (H = 128)
     int in = 0;
 };
 
@@ -267,6 +268,7 @@ int uvad_finalize(uvad_ctx *c) {
         const int in = k == 0 ? m.in_dim : H * D;
         const int inp = gemm_padded_k(in);   // rows zero-padded to the GEMM's K-step
         std::vector<float> wp((size_t)D * 4 * H * inp, 0.0f), bp((size_t)D * 4 * H), hh((size_t)D * whh_packed_elems(H));
+        std::vector<float> hh16((size_t)D * whh_packed_elems(H));
         for (int d = 0; d < D; ++d) {
             const std::string suf = "_l" + std::to_string(k) + (d ? "_reverse" : "");
             const HostTensor *wih = get("lstm.weight_ih" + suf), *whh = get("lstm.weight_hh" + suf);
@@ -283,6 +285,7 @@ int uvad_finalize(uvad_ctx *c) {
                     bp[dst] = bih->data[src] + bhh->data[src];
                 }
             pack_whh(whh->data.data(), H, &hh[(size_t)d * whh_packed_elems(H)]);
+            if (H == 128) pack_whh16(whh->data.data(), H, &hh16[(size_t)d * whh_packed_elems(H)]);
         }
         LayerDev &L = c->layers[k];
         L.in = in;
@@ -295,6 +298,7 @@ int uvad_finalize(uvad_ctx *c) {
         }
         if ((r = dev_upload(c, bp.data(), bp.size(), &L.bias))) return r;
         if ((r = dev_upload(c, hh.data(), hh.size(), &L.w_hh))) return r;
+        if (H == 128 && (r = dev_upload(c, hh16.data(), hh16.size(), &L.w_hh16))) return r;
     }
     c->lin_w.assign(m.lin_layers, nullptr);
     c->lin_b.assign(m.lin_layers, nullptr);
@@ -397,7 +401,7 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
             HIPCHK(c, run_gemm(g, s));
             if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k + 1], s));
             LstmArgs r{};
-            r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.Y = Y[k & 1]; r.ldy = w.Wd;
+            r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.Whh_packed16 = L.w_hh16; r.Y = Y[k & 1]; r.ldy = w.Wd;
             r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D;
             if (ss) {   // carried (h, c) of this layer, updated in place
                 r.h0 = r.hN = ss->h + (size_t)k * ss->layer_stride;

@@ -49,6 +49,7 @@ struct LstmArgs {
     const float *G; int ldg;
     const float *G2;             // optional second partial of the gate pre-activations (same layout), added to G
     const float *Whh_packed;     // per dir: register image, see pack_whh()
+    const float *Whh_packed16;   // per dir: register image of the 16-sequence kernel (pack_whh16), H = 128 only
     float *Y; int ldy;
     int tiles, T, H, dirs;
     int s_begin, s_count;        // steps [s_begin, s_begin + s_count) of the T-step recurrence (s_count 0 = all):
@@ -62,6 +63,7 @@ size_t whh_packed_elems(int H);
 int lstm_waves(int H);   // waves per recurrent workgroup (8 at H = 128: two per SIMD)
 // host-side packer: torch w_hh [4H][H] (rows i,f,g,o) -> register image
 void pack_whh(const float *w_hh, int H, float *out);
+void pack_whh16(const float *w_hh, int H, float *out);
 
 // ---- head.hip -----------------------------------------------------------------------------
 // logit = Z[m][:K] . w + b ; prob = sigmoid(logit); written at canonical [b][t] (b < B only).
