@@ -66,7 +66,8 @@ def main():
     assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())   # one rank per GPU (the modulo only matters
+                                                                         # when ranks are rehearsed on a 1-GPU box with gloo)
     torch.cuda.set_device(dev)
 
     B, S = args.batch, int(SECONDS * 16000)
