@@ -53,7 +53,25 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned &p1, unsi
     p3 = x3 | (y3 << 16);
 }
 
+#ifdef UVAD_GS_STAMP   // diagnostic build (tools/gemm_ablate.hip): cycle shares of one K-step
+#define GS_STAMP(i)                                                                        \
+    {                                                                                      \
+        unsigned long long t_;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        gs_acc[i] += t_ - gs_prev;                                                         \
+        gs_prev = t_;                                                                      \
+    }
+#else
+#define GS_STAMP(i)
+#endif
+
 __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmArgs a, int mt, int nt) {
+#ifdef UVAD_GS_STAMP
+    unsigned long long gs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gs_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gs_prev)::"memory");
+#endif
     __shared__ __attribute__((aligned(16))) unsigned short As[3][BM * LDH];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[3][BN * LDH];
 
@@ -89,15 +107,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmArgs a, int mt,
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
 
-    float4 ra0, ra1, ra2, ra3;
+    // A is streamed from HBM (every K-step of a row is a fresh 128-byte line: full memory latency), so
+    // its loads run TWO K-steps ahead (ra* = next step, rn* = the one after); the pre-split weights are
+    // L2-resident and run one step ahead.
+    float4 ra0, ra1, ra2, ra3, rn0, rn1, rn2, rn3;
     uint4 rw00, rw01, rw10, rw11, rw20, rw21;
-#define UVAD_GLOAD(k0)                                                                  \
+#define UVAD_GLOAD_A(R0_, R1_, R2_, R3_, k0)                                            \
     {                                                                                   \
         const int ka_ = ((k0) + skq * 4 < a.K) ? (k0) : -skq * 4;                       \
-        ra0 = *reinterpret_cast<const float4 *>(ap0 + ka_);                             \
-        ra1 = *reinterpret_cast<const float4 *>(ap1 + ka_);                             \
-        ra2 = *reinterpret_cast<const float4 *>(ap2 + ka_);                             \
-        ra3 = *reinterpret_cast<const float4 *>(ap3 + ka_);                             \
+        R0_ = *reinterpret_cast<const float4 *>(ap0 + ka_);                             \
+        R1_ = *reinterpret_cast<const float4 *>(ap1 + ka_);                             \
+        R2_ = *reinterpret_cast<const float4 *>(ap2 + ka_);                             \
+        R3_ = *reinterpret_cast<const float4 *>(ap3 + ka_);                             \
+    }
+#define UVAD_GLOAD_W(k0)                                                                \
+    {                                                                                   \
         rw00 = *reinterpret_cast<const uint4 *>(wp + (k0));                             \
         rw01 = *reinterpret_cast<const uint4 *>(wp + (k0) + 8);                         \
         rw10 = *reinterpret_cast<const uint4 *>(wp + plane + (k0));                     \
@@ -105,21 +129,33 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmArgs a, int mt,
         rw20 = *reinterpret_cast<const uint4 *>(wp + 2 * plane + (k0));                 \
         rw21 = *reinterpret_cast<const uint4 *>(wp + 2 * plane + (k0) + 8);             \
     }
-#define UVAD_SPLIT_STORE(RA, ROW)                                                       \
+    // split of the NEXT K-step's A values into packed bf16 pairs (VALU only: issued in the shadow of the
+    // current step's MFMAs, 24 of every 32 cycles of a 32x32x16 MFMA leave the vector issue port free)
+    uint2 q1_0, q2_0, q3_0, q1_1, q2_1, q3_1, q1_2, q2_2, q3_2, q1_3, q2_3, q3_3;
+#define UVAD_SPLIT(RA, Q1, Q2, Q3)                                                      \
     {                                                                                   \
-        uint2 q1, q2, q3;                                                               \
-        split3_pair(RA.x, RA.y, q1.x, q2.x, q3.x);                                      \
-        split3_pair(RA.z, RA.w, q1.y, q2.y, q3.y);                                      \
-        *reinterpret_cast<uint2 *>(&As[0][(ROW) * LDH + skq * 4]) = q1;                 \
-        *reinterpret_cast<uint2 *>(&As[1][(ROW) * LDH + skq * 4]) = q2;                 \
-        *reinterpret_cast<uint2 *>(&As[2][(ROW) * LDH + skq * 4]) = q3;                 \
+        split3_pair(RA.x, RA.y, Q1.x, Q2.x, Q3.x);                                      \
+        split3_pair(RA.z, RA.w, Q1.y, Q2.y, Q3.y);                                      \
+    }
+#define UVAD_SPLIT_ALL()                                                                \
+    {                                                                                   \
+        UVAD_SPLIT(ra0, q1_0, q2_0, q3_0)                                               \
+        UVAD_SPLIT(ra1, q1_1, q2_1, q3_1)                                               \
+        UVAD_SPLIT(ra2, q1_2, q2_2, q3_2)                                               \
+        UVAD_SPLIT(ra3, q1_3, q2_3, q3_3)                                               \
+    }
+#define UVAD_STORE_ROW(ROW, Q1, Q2, Q3)                                                 \
+    {                                                                                   \
+        *reinterpret_cast<uint2 *>(&As[0][(ROW) * LDH + skq * 4]) = Q1;                 \
+        *reinterpret_cast<uint2 *>(&As[1][(ROW) * LDH + skq * 4]) = Q2;                 \
+        *reinterpret_cast<uint2 *>(&As[2][(ROW) * LDH + skq * 4]) = Q3;                 \
     }
 #define UVAD_LSTORE()                                                                   \
     {                                                                                   \
-        UVAD_SPLIT_STORE(ra0, srow)                                                     \
-        UVAD_SPLIT_STORE(ra1, srow + 32)                                                \
-        UVAD_SPLIT_STORE(ra2, srow + 64)                                                \
-        UVAD_SPLIT_STORE(ra3, srow + 96)                                                \
+        UVAD_STORE_ROW(srow, q1_0, q2_0, q3_0)                                          \
+        UVAD_STORE_ROW(srow + 32, q1_1, q2_1, q3_1)                                     \
+        UVAD_STORE_ROW(srow + 64, q1_2, q2_2, q3_2)                                     \
+        UVAD_STORE_ROW(srow + 96, q1_3, q2_3, q3_3)                                     \
         *reinterpret_cast<uint4 *>(&Bs[0][brow * LDH + bhalf * 16]) = rw00;             \
         *reinterpret_cast<uint4 *>(&Bs[0][brow * LDH + bhalf * 16 + 8]) = rw01;         \
         *reinterpret_cast<uint4 *>(&Bs[1][brow * LDH + bhalf * 16]) = rw10;             \
@@ -129,14 +165,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmArgs a, int mt,
     }
 
     const int nk = (a.K + BK - 1) / BK;
-    UVAD_GLOAD(0)
+    UVAD_GLOAD_A(ra0, ra1, ra2, ra3, 0)
+    UVAD_GLOAD_W(0)
+    if (nk > 1) UVAD_GLOAD_A(rn0, rn1, rn2, rn3, BK)
+    UVAD_SPLIT_ALL()
     UVAD_LSTORE()
     __syncthreads();
 
+    GS_STAMP(0)   // [0] prologue: first loads, split, store, barrier
     const int fr = lane & 31, fh = lane >> 5;
     const int a_off = (wr * 64 + fr) * LDH + fh * 8, b_off = (wc * 64 + fr) * LDH + fh * 8;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) UVAD_GLOAD((kt + 1) * BK)
+        if (kt + 1 < nk) {
+            ra0 = rn0; ra1 = rn1; ra2 = rn2; ra3 = rn3;   // step kt+1 (issued one iteration ago)
+            UVAD_GLOAD_W((kt + 1) * BK)
+            if (kt + 2 < nk) UVAD_GLOAD_A(rn0, rn1, rn2, rn3, (kt + 2) * BK)
+        }
+        GS_STAMP(1)   // [1] issue of the global loads
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             bf16x8 fa[2][3], fb[2][3];
@@ -157,12 +202,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmArgs a, int mt,
             UVAD_SIX(acc10, 1, 0)
             UVAD_SIX(acc11, 1, 1)
         }
-        __syncthreads();
-        if (kt + 1 < nk) {
-            UVAD_LSTORE()
-            __syncthreads();
+        UVAD_SPLIT_ALL()   // VALU work of the next step (unconditional: same basic block as the MFMAs, so it can be
+                           // scheduled between them; on the last step it splits stale registers nobody stores)
+        // [12 fragment reads][24 x (1 MFMA + 3 VALU)] per 16-deep half step
+#pragma unroll
+        for (int hs = 0; hs < BK / 16; ++hs) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
         }
+        GS_STAMP(2)   // [2] fragment reads + 48 MFMAs (+ split of the next step)
+        __syncthreads();
+        GS_STAMP(3)   // [3] barrier after compute
+        // unconditional (also after the last step, where it stores stale data nobody reads): a branch here
+        // would let LLVM sink the split into it, away from the MFMAs it is meant to hide behind
+        UVAD_LSTORE()
+        GS_STAMP(4)   // [4] LDS store of the next step
+        __syncthreads();
+        GS_STAMP(5)   // [5] barrier after store
     }
+    GS_STAMP(6)
 
     // epilogue: identical to gemm.hip (C/D map of the 32x32 MFMA is dtype-independent)
     const bool full = R0 + BM <= Rend && C0 + BN <= a.N;
@@ -191,6 +253,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(GemmArgs a, int mt,
     UVAD_EPILOGUE(acc01, 0, 1)
     UVAD_EPILOGUE(acc10, 1, 0)
     UVAD_EPILOGUE(acc11, 1, 1)
+#ifdef UVAD_GS_STAMP
+    GS_STAMP(7)   // [7] epilogue
+    if (lane == 0 && blockIdx.x == 4000) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.C) + wave * 8;
+        for (int i = 0; i < 8; ++i) o[i] = gs_acc[i];
+    }
+#endif
 }
 
 }  // namespace
