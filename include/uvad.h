@@ -87,7 +87,7 @@ int uvad_set_tables(uvad_ctx *, const float *window, const float *mel);
  * "linear.0.weight", "classifier.bias", ...; an optional "model." Lightning prefix is stripped),
  * host pointer, row-major f32.  Replaces nn.Module.load_state_dict / VadModel.load_from_checkpoint
  * (src/scripts/predict.py:77). */
-int uvad_set_weight(uvad_ctx *, const char *torch_key, const float *host, const int64_t *shape, int ndim);
+int uvad_set_weight(uvad_ctx *, const char *torch_key, const float *host, const int64_t *shape, int ndim /* 1..3 */);
 
 /* Checks that every tensor is present, repacks into kernel layouts and uploads. */
 int uvad_finalize(uvad_ctx *);
@@ -149,6 +149,45 @@ int uvad_median_filter(uvad_ctx *, const float *d_probs, int B, int T, int kerne
  * FA / MD / DER are these counts divided by the row length (DER = FA + MD, vad_engine.py:102-105). */
 int uvad_der_counts(uvad_ctx *, const uint8_t *d_pred, const uint8_t *d_gt, int B, int T, uint32_t *d_counts,
                     void *stream);
+
+/* ---- SincNet front end (PyanNet) ------------------------------------------------------------
+ * Constructor arguments of SincNet (src/models/blocks/sincnet.py:33-70) as PyanNet builds it
+ * (src/models/segmentation/PyanNet.py:62, 91-95: stride 10). */
+typedef struct {
+    int stride;        /* hop of the sinc filter bank: SINCNET_DEFAULTS["stride"] = 10 */
+    int n_filters;     /* 80 (40 cos + 40 sin band-pass filters) */
+    int kernel_size;   /* 251 */
+    int c2, k2;        /* Conv1d(80, 60, 5) */
+    int c3, k3;        /* Conv1d(60, 60, 5); c3 must equal the classifier's encoding_dim */
+    float leaky_slope; /* F.leaky_relu default 0.01 */
+    float eps;         /* InstanceNorm1d eps 1e-5 */
+} uvad_sincnet_cfg;
+
+/* Replaces: SincNet.__init__ (sincnet.py:33-70).  Adds the stage to a context created with a model
+ * configuration; its tensors go through uvad_set_weight under their state_dict names
+ *   sincnet.wav_norm1d.{weight,bias} [1]      sincnet.norm1d.{0,1,2}.{weight,bias} [C]
+ *   sincnet.conv1d.{1,2}.weight [Cout][Cin][k]  sincnet.conv1d.{1,2}.bias [Cout]
+ * plus the MATERIALISED first-layer filter bank  sincnet.conv1d.0.filters [n_filters][kernel_size]
+ * (what asteroid_filterbanks.ParamSincFB.filters() returns from low_hz_ / band_hz_; the host computes it,
+ * see universal-voice-activity-detection_amd/sincnet.py), and uvad_finalize packs them. */
+int uvad_sincnet_configure(uvad_ctx *, const uvad_sincnet_cfg *);
+
+/* Output frames for S samples: three (conv, MaxPool1d(3)) stages; 80000 -> 293
+ * (src/datasets/custom_vad.py:47, src/utils/receptive_field.py:165-193). */
+int64_t uvad_sincnet_num_frames(const uvad_ctx *, int64_t S);
+
+/* Device workspace of uvad_sincnet (pooled activations + norm statistics) for B waveforms of S samples;
+ * uvad_forward_wav needs this plus uvad_workspace_bytes(ctx, B, frames). */
+size_t uvad_sincnet_workspace_bytes(const uvad_ctx *, int B, int64_t S);
+
+/* Replaces: SincNet.forward (sincnet.py:72-103) followed by the rearrange of PyanNet.forward (PyanNet.py:179).
+ * d_wav [B][S] f32 (the reference's (batch, 1, samples) tensor) -> d_feats [B][frames][c3]. */
+int uvad_sincnet(uvad_ctx *, const float *d_wav, int B, int64_t S, float *d_feats, void *d_workspace,
+                 size_t ws_bytes, void *stream);
+
+/* Replaces: PyanNet.forward (PyanNet.py:162-195): uvad_sincnet + uvad_classify; d_logits / d_probs [B][frames]. */
+int uvad_forward_wav(uvad_ctx *, const float *d_wav, int B, int64_t S, float *d_logits, float *d_probs,
+                     void *d_workspace, size_t ws_bytes, void *stream);
 
 /* Which kernel runs the time-parallel contractions (input projections, feed-forward layers):
  *   0  exact f32: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain, bit-compatible with f32 FMA arithmetic;

@@ -146,3 +146,86 @@ def synth_pcm(B, S, seed=1000, sample_rate=16000):
             x = x + 0.15 * env * sig
         out[i] = np.clip(x, -1.0, 1.0).astype(np.float32)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SincNet front end: reference src/models/blocks/sincnet.py:33-103, used by PyanNet.forward
+# (src/models/segmentation/PyanNet.py:162-195).  The first layer is asteroid_filterbanks.ParamSincFB
+# (requirements.txt:1, asteroid-filterbanks==0.4), which is NOT in this image: its filter construction is
+# restated below from the published algorithm (cos / sin band-pass pairs from learnable low / band edges, half
+# Hamming window, mel-spaced initialisation) and is PARITY UNPINNED; the layers after the filter bank are stock
+# torch modules (Conv1d / MaxPool1d / InstanceNorm1d / leaky_relu) and follow sincnet.py line by line.
+# Known answer pinned by the reference: 80000 samples -> 293 frames (src/datasets/custom_vad.py:47,
+# src/utils/receptive_field.py:165-193).
+
+def sinc_init_params(n_filters=80, sample_rate=16000.0, min_low_hz=50.0, min_band_hz=50.0):
+    """Mel-spaced initial (low_hz_, band_hz_) of ParamSincFB, each (n_filters/2, 1)."""
+    to_mel = lambda hz: 2595.0 * np.log10(1.0 + hz / 700.0)
+    to_hz = lambda mel: 700.0 * (10.0 ** (mel / 2595.0) - 1.0)
+    mel = np.linspace(to_mel(30.0), to_mel(sample_rate / 2 - (min_low_hz + min_band_hz)), n_filters // 2 + 1, dtype="float32")
+    hz = to_hz(mel).astype(np.float32)
+    return torch.from_numpy(hz[:-1]).view(-1, 1), torch.from_numpy(np.diff(hz)).view(-1, 1)
+
+
+def sinc_filters(low_hz_, band_hz_, kernel_size=251, sample_rate=16000.0, min_low_hz=50.0, min_band_hz=50.0):
+    """(n_filters, kernel_size) f32: [cos filters ; sin filters]."""
+    half = kernel_size // 2
+    window = torch.from_numpy(np.hamming(kernel_size)[:half].astype(np.float32))
+    n_ = 2 * np.pi * (torch.arange(-half, 0.0).view(1, -1) / sample_rate)
+    low = min_low_hz + torch.abs(low_hz_.float())
+    high = torch.clamp(low + min_band_hz + torch.abs(band_hz_.float()), min_low_hz, sample_rate / 2)
+    band = (high - low)[:, 0]
+    ft_low, ft_high = torch.matmul(low, n_), torch.matmul(high, n_)
+    cos_left = ((torch.sin(ft_high) - torch.sin(ft_low)) / (n_ / 2)) * window
+    cos = torch.cat([cos_left, 2 * band.view(-1, 1), torch.flip(cos_left, dims=[1])], dim=1) / (2 * band[:, None])
+    sin_left = ((torch.cos(ft_low) - torch.cos(ft_high)) / (n_ / 2)) * window
+    sin = torch.cat([sin_left, torch.zeros_like(band.view(-1, 1)), -torch.flip(sin_left, dims=[1])], dim=1) / (2 * band[:, None])
+    return torch.cat([cos, sin], dim=0).float()
+
+
+def sincnet_num_frames(S, stride=10):
+    n = (S - 251) // stride + 1
+    n = n // 3
+    n = (n - 4) // 3
+    n = (n - 4) // 3
+    return n
+
+
+class TorchSincNet(nn.Module):
+    """sincnet.py:33-103 on stock torch modules; the sinc layer is a conv1d with the materialised filter bank."""
+
+    def __init__(self, stride=10):
+        super().__init__()
+        self.stride = stride
+        self.wav_norm1d = nn.InstanceNorm1d(1, affine=True)
+        low, band = sinc_init_params()
+        self.low_hz_ = nn.Parameter(low)
+        self.band_hz_ = nn.Parameter(band)
+        self.norm1d = nn.ModuleList([nn.InstanceNorm1d(80, affine=True), nn.InstanceNorm1d(60, affine=True), nn.InstanceNorm1d(60, affine=True)])
+        self.conv1d = nn.ModuleList([nn.Conv1d(80, 60, 5), nn.Conv1d(60, 60, 5)])   # conv1d.1 / conv1d.2 of the reference
+
+    @torch.no_grad()
+    def forward(self, wav):   # (B, 1, S) -> (B, 60, frames)
+        x = self.wav_norm1d(wav)
+        x = F.conv1d(x, sinc_filters(self.low_hz_, self.band_hz_).unsqueeze(1), stride=self.stride)
+        x = torch.abs(x)
+        x = F.leaky_relu(self.norm1d[0](F.max_pool1d(x, 3, 3)))
+        x = F.leaky_relu(self.norm1d[1](F.max_pool1d(self.conv1d[0](x), 3, 3)))
+        x = F.leaky_relu(self.norm1d[2](F.max_pool1d(self.conv1d[1](x), 3, 3)))
+        return x
+
+
+def seeded_sincnet(seed=99):
+    g = torch.Generator().manual_seed(seed)
+    m = TorchSincNet()
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name in ("low_hz_", "band_hz_"):
+                p.mul_(1.0 + 0.05 * (torch.rand(p.shape, generator=g) - 0.5))       # perturb the mel initialisation
+            elif "norm" in name and name.endswith("weight"):
+                p.copy_(1.0 + 0.2 * (torch.rand(p.shape, generator=g) - 0.5))
+            elif "norm" in name:
+                p.copy_(0.2 * (torch.rand(p.shape, generator=g) - 0.5))
+            else:
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) / math.sqrt(p.shape[1] * p.shape[2] if p.dim() == 3 else 300.0))
+    return m.eval()

@@ -1,0 +1,133 @@
+"""GPU parity tests (-m gpu) of the SincNet front end and the PyanNet waveform model, through
+the C ABI (uvad_sincnet / uvad_forward_wav) against the torch-CPU restatement in oracle/torch_ref.py
+(TorchSincNet: sincnet.py:33-103 on stock Conv1d / MaxPool1d / InstanceNorm1d; ParamSincFB restated, PARITY
+UNPINNED for the filter construction only -- the conv stack is checked with the filter bank as given).
+
+Tolerances: SincNet features (instance-normalised, O(1)) 1e-4 max-abs; PyanNet logits 1e-4 max-abs
+(BASELINE.json north_star) at the sizes run here."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FEAT_TOL = 1e-4
+LOGIT_TOL = 1e-4
+
+
+def _pair(seed=99, lstm=None):
+    """(torch-CPU oracle front end, oracle classifier, uvad_amd.PyanNet with the same weights on the GPU)."""
+    import uvad_amd
+    from oracle import torch_ref as tr
+    front = tr.seeded_sincnet(seed)
+    lstm = lstm or {}
+    hidden, layers, bidir = lstm.get("hidden_size", 128), lstm.get("num_layers", 4), lstm.get("bidirectional", True)
+    csd = tr.seeded_state_dict(60, hidden, layers, bidir, seed=4321, scale=4.0)
+    cls = tr.TorchPyanNet2(60, hidden, layers, bidir)
+    cls.load_state_dict(csd)
+    m = uvad_amd.PyanNet(lstm=lstm)
+    m.build()
+    sd = dict(csd)
+    fsd = front.state_dict()
+    for k in ("wav_norm1d.weight", "wav_norm1d.bias"):
+        sd["sincnet." + k] = fsd[k]
+    sd["sincnet.conv1d.0.filterbank.low_hz_"] = fsd["low_hz_"]
+    sd["sincnet.conv1d.0.filterbank.band_hz_"] = fsd["band_hz_"]
+    for i in range(3):
+        for p in ("weight", "bias"):
+            sd[f"sincnet.norm1d.{i}.{p}"] = fsd[f"norm1d.{i}.{p}"]
+    for i in range(2):
+        for p in ("weight", "bias"):
+            sd[f"sincnet.conv1d.{i + 1}.{p}"] = fsd[f"conv1d.{i}.{p}"]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("filterbank" in k for k in missing), (missing, unexpected)   # only asteroid's buffers
+    return front, cls.eval(), m.to("cuda:0").eval()
+
+
+@pytest.mark.parametrize("B,S", [(3, 32000 + 37), (1, 80000), (5, 4000), (2, 1000)])
+def test_sincnet_features_match_oracle(B, S):
+    from oracle import torch_ref as tr
+    front, _, m = _pair()
+    wav = torch.from_numpy(tr.synth_pcm(B, S, seed=77))
+    want = front(wav.unsqueeze(1)).transpose(1, 2).numpy()       # (B, frames, 60)
+    got = m.runtime(torch.device("cuda:0")).sincnet(wav.cuda())
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (B, tr.sincnet_num_frames(S), 60)
+    err = np.abs(got.cpu().numpy() - want).max()
+    print(f"SincNet B={B} S={S}: frames {want.shape[1]} max-abs feature err {err:.2e} (|feat| max {np.abs(want).max():.2f})")
+    assert err < FEAT_TOL
+    # reference layout (batch, feature, frames) through the module tree
+    out = m.sincnet(wav.cuda().unsqueeze(1))
+    assert out.shape == (B, 60, want.shape[1]) and torch.equal(out.transpose(1, 2), got)
+
+
+def test_pyannet_forward_matches_oracle_and_5s_cut_gives_293_frames():
+    from oracle import torch_ref as tr
+    front, cls, m = _pair()
+    wav = torch.from_numpy(tr.synth_pcm(4, 80000, seed=5))
+    feats = front(wav.unsqueeze(1)).transpose(1, 2).contiguous()
+    want_logits, want_probs = cls(feats)
+    logits, probs = m.forward_logits(wav.cuda().unsqueeze(1))
+    torch.cuda.synchronize()
+    assert logits.shape == (4, 293)
+    err = (logits.cpu() - want_logits).abs().max().item()
+    perr = (probs.cpu() - want_probs).abs().max().item()
+    print(f"PyanNet 4 x 5 s: max-abs logit err {err:.2e} prob err {perr:.2e} (logit range {want_logits.min():.2f}..{want_logits.max():.2f})")
+    assert err < LOGIT_TOL and perr < LOGIT_TOL
+    out = m(wav.cuda().unsqueeze(1))
+    assert out.shape == (4, 293, 1) and torch.equal(out.squeeze(-1), probs)
+
+
+def test_sincnet_batch_invariance_and_determinism():
+    """An utterance's features do not depend on its batch neighbours or on scheduling (tile-ordered statistics)."""
+    from oracle import torch_ref as tr
+    _, _, m = _pair()
+    rt = m.runtime(torch.device("cuda:0"))
+    wav = torch.from_numpy(tr.synth_pcm(48, 24000, seed=300)).cuda()
+    full = rt.sincnet(wav).clone()
+    again = rt.sincnet(wav).clone()
+    single = rt.sincnet(wav[17:18]).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(full, again)
+    assert torch.equal(full[17:18], single)
+
+
+def test_sincnet_errors_are_loud():
+    import uvad_amd
+    from uvad_amd._lib import UvadError
+    _, _, m = _pair()
+    rt = m.runtime(torch.device("cuda:0"))
+    with pytest.raises(ValueError, match="too short"):
+        rt.sincnet(torch.zeros(1, 700, device="cuda:0"))
+    with pytest.raises(RuntimeError, match="must be a tensor on"):
+        rt.sincnet(torch.zeros(1, 16000))
+    # a runtime without the SincNet tensors refuses to run the stage
+    m2 = uvad_amd.PyanNet2(encoding_dim=60)
+    m2.build()
+    with pytest.raises(RuntimeError, match="without a SincNet"):
+        m2.to("cuda:0").runtime(torch.device("cuda:0")).sincnet(torch.zeros(1, 16000, device="cuda:0"))
+    with pytest.raises(UvadError, match="encoding_dim"):
+        uvad_amd.VadRuntime(device="cuda:0", model={"encoding_dim": 64, "lstm": m.hparams.lstm, "linear": m.hparams.linear},
+                            sincnet=m.sincnet.config())
+
+
+def test_vadmodel_pyannet_predict_step():
+    """VadModel(model_name="PyanNet"): batch["inputs"] is (batch, samples); _common_step adds the channel axis
+    (vad_engine.py:252-255); predict_step = threshold + 49-tap median of the probabilities."""
+    import uvad_amd
+    from oracle import torch_ref as tr
+    from oracle import c_oracle
+    front, cls, m = _pair(lstm={"num_layers": 2})
+    vm = uvad_amd.VadModel(model_name="PyanNet", model_dict={"lstm": {"num_layers": 2}})
+    vm.model.load_state_dict(m.state_dict())
+    vm = vm.to("cuda:0")
+    wav = torch.from_numpy(tr.synth_pcm(2, 48000, seed=9))
+    labels = vm.predict_step({"inputs": wav.cuda()}, 0)
+    torch.cuda.synchronize()
+    _, want_probs = cls(front(wav.unsqueeze(1)).transpose(1, 2).contiguous())
+    want = c_oracle.median_filter(want_probs.numpy(), 49)
+    got = labels.squeeze(-1).cpu().numpy()
+    assert labels.shape == (2, want.shape[1], 1)
+    # labels may differ only where a probability sits within tolerance of the 0.5 threshold
+    near = np.abs(want_probs.numpy() - 0.5) < 1e-3
+    assert (got != want).sum() <= near.sum()

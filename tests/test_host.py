@@ -41,8 +41,31 @@ def test_pyannet2_variants():
     assert "lstm.3.weight_hh_l0_reverse" in m2.state_dict()
     with pytest.raises(RuntimeError, match="build"):
         uvad_amd.PyanNet2(encoding_dim=64).runtime(torch.device("cuda:0"))
-    with pytest.raises(NotImplementedError):
-        uvad_amd.PyanNet()
+
+
+def test_pyannet_mirror_state_dict_and_frame_count():
+    """PyanNet (SincNet front end): the reference's state_dict names / shapes, 293 frames per 5 s cut
+    (src/datasets/custom_vad.py:47) and no CPU path."""
+    m = uvad_amd.PyanNet()
+    m.build()
+    sd = m.state_dict()
+    for k, shape in {"sincnet.wav_norm1d.weight": (1,), "sincnet.conv1d.0.filterbank.low_hz_": (40, 1),
+                     "sincnet.conv1d.0.filterbank.band_hz_": (40, 1), "sincnet.conv1d.1.weight": (60, 80, 5),
+                     "sincnet.conv1d.2.bias": (60,), "sincnet.norm1d.0.weight": (80,), "sincnet.norm1d.2.bias": (60,),
+                     "lstm.weight_ih_l0": (512, 60), "classifier.weight": (1, 128)}.items():
+        assert tuple(sd[k].shape) == shape, k
+    assert m.hparams.sincnet == {"stride": 10, "sample_rate": 16000}
+    assert m.num_frames(80000) == 293 and tr.sincnet_num_frames(80000) == 293
+    f = m.sincnet.conv1d[0].filterbank.filters()
+    assert tuple(f.shape) == (80, 1, 251)
+    # host filter construction == the oracle's restatement of ParamSincFB.filters()
+    assert torch.equal(f[:, 0, :], tr.sinc_filters(m.sincnet.conv1d[0].filterbank.low_hz_.detach(), m.sincnet.conv1d[0].filterbank.band_hz_.detach()))
+    # cos filters are even, sin filters odd, DC gain of a band-pass is ~0 relative to its peak
+    assert torch.allclose(f[:40, 0], torch.flip(f[:40, 0], dims=[1])) and torch.allclose(f[40:, 0], -torch.flip(f[40:, 0], dims=[1]))
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(torch.zeros(1, 1, 16000))
+    with pytest.raises(RuntimeError, match="PyanNet"):
+        m.sincnet.__class__()(torch.zeros(1, 1, 16000))
 
 
 def test_seed_weights_equals_golden_generator_weights():

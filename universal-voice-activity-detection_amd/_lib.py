@@ -25,6 +25,11 @@ class ModelCfg(C.Structure):
                 ("leaky_slope", C.c_float)]
 
 
+class SincNetCfg(C.Structure):
+    _fields_ = [("stride", C.c_int), ("n_filters", C.c_int), ("kernel_size", C.c_int), ("c2", C.c_int), ("k2", C.c_int),
+                ("c3", C.c_int), ("k3", C.c_int), ("leaky_slope", C.c_float), ("eps", C.c_float)]
+
+
 class UvadError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
@@ -46,6 +51,12 @@ SIGNATURES = {
                                 C.c_void_p, C.c_size_t, C.c_void_p]),
     "uvad_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_size_t, C.c_void_p]),
+    "uvad_sincnet_configure": (C.c_int, [C.c_void_p, C.POINTER(SincNetCfg)]),
+    "uvad_sincnet_num_frames": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "uvad_sincnet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int64]),
+    "uvad_sincnet": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "uvad_forward_wav": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     "uvad_get_taps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uvad_stream_state_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "uvad_stream_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),

@@ -53,6 +53,12 @@ struct uvad_ctx {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ovl_ev;
     float *cls_w = nullptr, *cls_b = nullptr;
+    // SincNet front end (sincnet.hip)
+    bool has_sinc = false, sinc_ready = false;
+    uvad_sincnet_cfg sc{};
+    float *sn_wav_g = nullptr, *sn_wav_b = nullptr;
+    float *sn_wt[3] = {nullptr, nullptr, nullptr}, *sn_bias[3] = {nullptr, nullptr, nullptr};
+    float *sn_g[3] = {nullptr, nullptr, nullptr}, *sn_b[3] = {nullptr, nullptr, nullptr};
     std::vector<void *> allocs;
     // timing
     bool timing = false;
@@ -122,9 +128,44 @@ WsLayout carve(const uvad_ctx *c, int B, int64_t T) {
     for (int i = 0; i < 2; ++i) { w.off_state[i] = o; o += align_up((size_t)w.D * w.tiles * SEQ_TILE * m.hidden * sizeof(float)); }
     for (int i = 0; i < 2; ++i) { w.off_Y[i] = o; o += align_up(w.M * w.Wd * sizeof(float)); }
     for (int i = 0; i < 2; ++i) { w.off_Z[i] = o; o += align_up(w.M * (size_t)(m.lin_layers > 0 ? m.lin_hidden : 0) * sizeof(float)); }
-    w.off_feats = o; o += align_up((size_t)B * T * (c->has_fb ? (size_t)c->fb.n_mels : (size_t)m.in_dim) * sizeof(float));
+    w.off_feats = o; o += align_up((size_t)B * T * (size_t)(c->has_fb && c->fb.n_mels > m.in_dim ? c->fb.n_mels : m.in_dim) * sizeof(float));
     w.total = o;
     return w;
+}
+
+// SincNet stage geometry and workspace for B waveforms of S samples.
+struct SincLayout {
+    int Cin[3], Cout[3], Kw[3], stride[3], NW[3];
+    int64_t Lin[3], Lconv[3], Lpool[3];
+    int ntiles[3];
+    size_t off_s0 = 0, off_P[3] = {0, 0, 0}, off_part[3] = {0, 0, 0}, off_sc[3] = {0, 0, 0}, total = 0;
+    bool ok = false;
+};
+SincLayout sinc_carve(const uvad_ctx *c, int B, int64_t S) {
+    SincLayout l;
+    const uvad_sincnet_cfg &q = c->sc;
+    const int cin[3] = {1, q.n_filters, q.c2}, cout[3] = {q.n_filters, q.c2, q.c3}, kw[3] = {q.kernel_size, q.k2, q.k3};
+    int64_t L = S;
+    l.ok = true;
+    for (int i = 0; i < 3; ++i) {
+        l.Cin[i] = cin[i]; l.Cout[i] = cout[i]; l.Kw[i] = kw[i]; l.stride[i] = i == 0 ? q.stride : 1;
+        l.NW[i] = (cout[i] + 31) / 32 * 32;
+        l.Lin[i] = L;
+        l.Lconv[i] = L >= kw[i] ? (L - kw[i]) / l.stride[i] + 1 : 0;
+        l.Lpool[i] = l.Lconv[i] / 3;
+        l.ntiles[i] = (int)((l.Lpool[i] + 31) / 32);
+        if (l.Lpool[i] <= 0) l.ok = false;
+        L = l.Lpool[i];
+    }
+    size_t o = 0;
+    l.off_s0 = o; o += align_up((size_t)2 * B * sizeof(float));
+    for (int i = 0; i < 3; ++i) {
+        l.off_P[i] = o; o += align_up((size_t)B * l.Cout[i] * (size_t)(l.ok ? l.Lpool[i] : 0) * sizeof(float));
+        l.off_part[i] = o; o += align_up((size_t)B * (size_t)(l.ok ? l.ntiles[i] : 0) * l.NW[i] * 2 * sizeof(float));
+        l.off_sc[i] = o; o += align_up((size_t)2 * B * l.Cout[i] * sizeof(float));
+    }
+    l.total = o;
+    return l;
 }
 
 std::string strip_prefix(const char *key) {
@@ -238,7 +279,7 @@ int uvad_set_tables(uvad_ctx *c, const float *window, const float *mel) {
 }
 
 int uvad_set_weight(uvad_ctx *c, const char *torch_key, const float *host, const int64_t *shape, int ndim) {
-    if (!c || !torch_key || !host || !shape || ndim < 1 || ndim > 2) return UVAD_E_ARG;
+    if (!c || !torch_key || !host || !shape || ndim < 1 || ndim > 3) return UVAD_E_ARG;
     if (!c->has_model) return fail(c, UVAD_E_STATE, "context was created without a model configuration");
     HostTensor t;
     size_t n = 1;
@@ -333,8 +374,139 @@ int uvad_finalize(uvad_ctx *c) {
     if (!c->side) HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     c->ovl_ev.resize((size_t)m.num_layers * 9 + 2);
     for (auto &ev : c->ovl_ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    c->sinc_ready = false;
+    if (c->has_sinc && get("sincnet.conv1d.0.filters")) {   // the stage is optional: packed only when its tensors were given
+        const uvad_sincnet_cfg &q = c->sc;
+        const HostTensor *wg = get("sincnet.wav_norm1d.weight"), *wb = get("sincnet.wav_norm1d.bias");
+        if (!wg || !wb || !expect_shape(*wg, {1}) || !expect_shape(*wb, {1})) return fail(c, UVAD_E_STATE, "missing / misshaped sincnet.wav_norm1d tensors");
+        if ((r = dev_upload(c, wg->data.data(), 1, &c->sn_wav_g))) return r;
+        if ((r = dev_upload(c, wb->data.data(), 1, &c->sn_wav_b))) return r;
+        const int cin[3] = {1, q.n_filters, q.c2}, cout[3] = {q.n_filters, q.c2, q.c3}, kw[3] = {q.kernel_size, q.k2, q.k3};
+        for (int i = 0; i < 3; ++i) {
+            const std::string id = std::to_string(i);
+            const HostTensor *w = get(i == 0 ? std::string("sincnet.conv1d.0.filters") : "sincnet.conv1d." + id + ".weight");
+            const HostTensor *b = i == 0 ? nullptr : get("sincnet.conv1d." + id + ".bias");
+            const HostTensor *g = get("sincnet.norm1d." + id + ".weight"), *be = get("sincnet.norm1d." + id + ".bias");
+            if (!w || (i > 0 && !b) || !g || !be) return fail(c, UVAD_E_STATE, "missing sincnet tensors of stage " + id);
+            const bool wshape = i == 0 ? (expect_shape(*w, {cout[0], kw[0]}) || expect_shape(*w, {cout[0], 1, kw[0]})) : expect_shape(*w, {cout[i], cin[i], kw[i]});
+            if (!wshape || (b && !expect_shape(*b, {cout[i]})) || !expect_shape(*g, {cout[i]}) || !expect_shape(*be, {cout[i]}))
+                return fail(c, UVAD_E_ARG, "sincnet stage " + id + " tensor shape mismatch");
+            // W[n][k = ci*Kw + kw] -> [Kp/2][NW][2], zero padded in n and k (sincnet.hip B-operand layout)
+            const int Ktot = cin[i] * kw[i], Kp = (Ktot + 1) / 2 * 2, NW = (cout[i] + 31) / 32 * 32;
+            std::vector<float> wt((size_t)Kp * NW, 0.0f), bias((size_t)NW, 0.0f);
+            for (int n = 0; n < cout[i]; ++n) {
+                for (int k = 0; k < Ktot; ++k) wt[((size_t)(k >> 1) * NW + n) * 2 + (k & 1)] = w->data[(size_t)n * Ktot + k];
+                if (b) bias[n] = b->data[n];
+            }
+            if ((r = dev_upload(c, wt.data(), wt.size(), &c->sn_wt[i]))) return r;
+            if ((r = dev_upload(c, bias.data(), bias.size(), &c->sn_bias[i]))) return r;
+            if ((r = dev_upload(c, g->data.data(), g->data.size(), &c->sn_g[i]))) return r;
+            if ((r = dev_upload(c, be->data.data(), be->data.size(), &c->sn_b[i]))) return r;
+        }
+        c->sinc_ready = true;
+    }
     c->finalized = true;
     return UVAD_OK;
+}
+
+int uvad_sincnet_configure(uvad_ctx *c, const uvad_sincnet_cfg *q) {
+    if (!c || !q) return UVAD_E_ARG;
+    if (!c->has_model) return fail(c, UVAD_E_STATE, "uvad_sincnet_configure: context was created without a model configuration");
+    if (q->stride < 1 || q->kernel_size < 2 || q->k2 < 2 || q->k3 < 2 || q->n_filters < 1 || q->c2 < 1 || q->c3 < 1)
+        return fail(c, UVAD_E_ARG, "bad SincNet configuration");
+    const int cout[3] = {q->n_filters, q->c2, q->c3};
+    for (int i = 0; i < 3; ++i)
+        if (cout[i] <= 32 || cout[i] > 96) return fail(c, UVAD_E_UNSUPPORTED, "SincNet channel counts must be in 33..96 (two or three 32-wide MFMA column tiles)");
+    if (q->c3 != c->mc.in_dim) return fail(c, UVAD_E_ARG, "SincNet output channels != classifier encoding_dim");
+    // LDS budget of the widest stage (filter matrix + staging window), 160 KiB per CU
+    const int cin[3] = {1, q->n_filters, q->c2}, kw[3] = {q->kernel_size, q->k2, q->k3};
+    for (int i = 0; i < 3; ++i) {
+        SincConvArgs a{};
+        a.Cin = cin[i]; a.Kw = kw[i]; a.stride = i == 0 ? q->stride : 1; a.Ktot = cin[i] * kw[i]; a.Kp = (a.Ktot + 1) / 2 * 2;
+        if (sinc_conv_lds_bytes(a, (cout[i] + 31) / 32) > (size_t)160 * 1024)
+            return fail(c, UVAD_E_UNSUPPORTED, "SincNet stage does not fit the 160 KiB LDS (filter matrix is LDS-resident)");
+    }
+    c->sc = *q;
+    c->has_sinc = true;
+    c->sinc_ready = false;
+    c->finalized = false;
+    return UVAD_OK;
+}
+
+int64_t uvad_sincnet_num_frames(const uvad_ctx *c, int64_t S) {
+    if (!c || !c->has_sinc || S < 0) return -1;
+    const SincLayout l = sinc_carve(c, 1, S);
+    return l.ok ? l.Lpool[2] : 0;
+}
+
+size_t uvad_sincnet_workspace_bytes(const uvad_ctx *c, int B, int64_t S) {
+    if (!c || !c->has_sinc || B <= 0 || S <= 0) return 0;
+    return sinc_carve(c, B, S).total;
+}
+
+static int sincnet_impl(uvad_ctx *c, const float *d_wav, int B, int64_t S, float *d_feats, void *ws, size_t ws_bytes, hipStream_t s) {
+    if (!c->has_sinc) return fail(c, UVAD_E_STATE, "uvad_sincnet: uvad_sincnet_configure has not been called");
+    if (!c->finalized || !c->sinc_ready) return fail(c, UVAD_E_STATE, "uvad_sincnet: SincNet tensors not set / uvad_finalize not called");
+    if (B > 65535) return fail(c, UVAD_E_UNSUPPORTED, "uvad_sincnet: B > 65535 (grid.y); split the batch");
+    const SincLayout l = sinc_carve(c, B, S);
+    if (!l.ok) return fail(c, UVAD_E_ARG, "uvad_sincnet: waveform too short for one output frame");
+    if (l.Lconv[0] > 0x7fffffff / 4) return fail(c, UVAD_E_UNSUPPORTED, "uvad_sincnet: waveform too long");
+    if (ws_bytes < l.total) return fail(c, UVAD_E_WORKSPACE, "workspace too small: need " + std::to_string(l.total) + " bytes");
+    char *base = reinterpret_cast<char *>(ws);
+    const uvad_sincnet_cfg &q = c->sc;
+    float *s0 = reinterpret_cast<float *>(base + l.off_s0);
+    HIPCHK(c, launch_wav_stats(d_wav, B, S, S, c->sn_wav_g, c->sn_wav_b, q.eps, s0, s0 + B, s));
+    const float *in = d_wav, *in_scale = s0, *in_shift = s0 + B;
+    for (int i = 0; i < 3; ++i) {
+        float *P = reinterpret_cast<float *>(base + l.off_P[i]);
+        float *part = reinterpret_cast<float *>(base + l.off_part[i]);
+        float *sc = reinterpret_cast<float *>(base + l.off_sc[i]);
+        SincConvArgs a{};
+        a.in = in; a.in_bstride = (long long)l.Cin[i] * l.Lin[i]; a.Cin = l.Cin[i]; a.Lin = (int)l.Lin[i];
+        a.in_scale = in_scale; a.in_shift = in_shift; a.in_lrelu = i > 0; a.slope = q.leaky_slope;
+        a.Wt2 = c->sn_wt[i]; a.bias = c->sn_bias[i];
+        a.Kw = l.Kw[i]; a.stride = l.stride[i]; a.Ktot = l.Cin[i] * l.Kw[i]; a.Kp = (a.Ktot + 1) / 2 * 2; a.Cout = l.Cout[i]; a.do_abs = i == 0;
+        a.Lconv = (int)l.Lconv[i]; a.Lpool = (int)l.Lpool[i]; a.ntiles = l.ntiles[i];
+        a.out = P; a.partials = part; a.B = B;
+        HIPCHK(c, launch_sinc_conv(a, s));
+        HIPCHK(c, launch_norm_finalize(part, B, l.ntiles[i], l.NW[i], l.Cout[i], (int)l.Lpool[i], c->sn_g[i], c->sn_b[i], q.eps, sc,
+                                       sc + (size_t)B * l.Cout[i], s));
+        in = P; in_scale = sc; in_shift = sc + (size_t)B * l.Cout[i];
+    }
+    HIPCHK(c, launch_sinc_out(in, in_scale, in_shift, B, l.Cout[2], (int)l.Lpool[2], q.leaky_slope, d_feats, l.Cout[2], s));
+    return UVAD_OK;
+}
+
+int uvad_sincnet(uvad_ctx *c, const float *d_wav, int B, int64_t S, float *d_feats, void *ws, size_t ws_bytes, void *stream) {
+    if (!c) return UVAD_E_ARG;
+    if (!d_wav || !d_feats || B <= 0 || S <= 0 || !ws) return fail(c, UVAD_E_ARG, "uvad_sincnet: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    return sincnet_impl(c, d_wav, B, S, d_feats, ws, ws_bytes, (hipStream_t)stream);
+}
+
+static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float *d_logits, float *d_probs,
+                         void *ws, size_t ws_bytes, hipStream_t s, bool record_start,
+                         const StreamState *ss, int ld_out);
+
+int uvad_forward_wav(uvad_ctx *c, const float *d_wav, int B, int64_t S, float *d_logits, float *d_probs,
+                     void *ws, size_t ws_bytes, void *stream) {
+    if (!c) return UVAD_E_ARG;
+    if (!d_wav || B <= 0 || S <= 0 || !ws) return fail(c, UVAD_E_ARG, "uvad_forward_wav: bad argument");
+    if (!c->has_sinc) return fail(c, UVAD_E_STATE, "uvad_forward_wav: uvad_sincnet_configure has not been called");
+    if (!c->finalized) return fail(c, UVAD_E_STATE, "uvad_forward_wav: uvad_finalize has not been called");
+    const int64_t T = uvad_sincnet_num_frames(c, S);
+    if (T <= 0 || T > 0x7fffffff) return fail(c, UVAD_E_ARG, "uvad_forward_wav: waveform too short for one output frame");
+    const WsLayout w = carve(c, B, T);
+    const size_t sn = sinc_carve(c, B, S).total;
+    if (ws_bytes < w.total + sn) return fail(c, UVAD_E_WORKSPACE, "workspace too small: need " + std::to_string(w.total + sn) + " bytes");
+    char *base = reinterpret_cast<char *>(ws);
+    float *feats = reinterpret_cast<float *>(base + w.off_feats);
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
+    int r = sincnet_impl(c, d_wav, B, S, feats, base + w.total, ws_bytes - w.total, s);
+    if (r) return r;
+    return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, w.total, s, false, nullptr, 0);
 }
 
 int64_t uvad_num_frames(const uvad_ctx *c, int64_t S) {

@@ -87,12 +87,15 @@ class PyanNet2(nn.Module):
             if self._rt is not None:
                 self._rt.close()
             model = {"encoding_dim": self.encoding_dim, "lstm": self.hparams.lstm, "linear": self.hparams.linear}
-            rt = VadRuntime(device=device, fbank=self._fbank_cfg, model=model)
+            rt = VadRuntime(device=device, fbank=self._fbank_cfg, model=model, **self._runtime_extra())
             rt.load_state_dict(self._flat_state_dict())
             self._rt, self._rt_stamp = rt, stamp
         return self._rt
 
     _fbank_cfg = None
+
+    def _runtime_extra(self) -> dict:
+        return {}
 
     def attach_fbank(self, config):
         """Optional: give the model a FbankConfig so ``forward_waveform`` can run the fused
@@ -131,9 +134,55 @@ class PyanNet2(nn.Module):
         return self.runtime(pcm.device).forward(pcm)
 
 
-class PyanNet(nn.Module):
-    """The SincNet waveform model (src/models/segmentation/PyanNet.py) is the alternative front end,
-    not the log-mel path this package accelerates."""
+class PyanNet(PyanNet2):
+    """Mirror of src/models/segmentation/PyanNet.py:37-195: SincNet front end on the raw waveform, then the same
+    LSTM / feed-forward / classifier stack as PyanNet2 with ``encoding_dim`` = 60.  ``forward`` takes the
+    reference's (batch, channel = 1, samples) tensor ON THE GPU and returns (batch, frames, 1) probabilities;
+    the whole pass is ``uvad_forward_wav`` (csrc/sincnet.hip + the classifier kernels)."""
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("PyanNet (SincNet front end) is outside the accelerated log-mel path; use PyanNet2")
+    SINCNET_DEFAULTS = {"stride": 10}
+
+    def __init__(self, sincnet: dict = None, lstm: dict = None, linear: dict = None, encoding_dim: int = 60,
+                 sample_rate: int = 16000, num_channels: int = 1):
+        super().__init__(lstm=lstm, linear=linear, encoding_dim=encoding_dim, sample_rate=sample_rate, num_channels=num_channels)
+        from .sincnet import SincNet
+        sn = _merged(self.SINCNET_DEFAULTS, sincnet)
+        sn["sample_rate"] = sample_rate
+        self.hparams["sincnet"] = sn
+        self.sincnet = SincNet(**sn)
+        self.sincnet._run = self._sincnet_features
+
+    def _sincnet_features(self, wav2d):
+        self._require_gpu(wav2d, "waveforms")
+        return self.runtime(wav2d.device).sincnet(wav2d)
+
+    def _runtime_extra(self) -> dict:
+        return {"sincnet": self.sincnet.config()}
+
+    def _flat_state_dict(self):
+        sd = super()._flat_state_dict()
+        sd["sincnet.conv1d.0.filters"] = self.sincnet.conv1d[0].filterbank.filters()[:, 0, :]
+        return sd
+
+    def num_frames(self, num_samples: int) -> int:
+        return self.sincnet.num_frames(num_samples, self.sincnet.stride)
+
+    @torch.no_grad()
+    def forward(self, waveforms: torch.Tensor) -> torch.Tensor:
+        """(batch, channel, samples) -> (batch, frames, 1) speech probabilities."""
+        _, probs = self.forward_logits(waveforms, want_logits=False)
+        return probs.unsqueeze(-1)
+
+    @torch.no_grad()
+    def forward_logits(self, waveforms: torch.Tensor, want_logits=True):
+        self._require_gpu(waveforms, "waveforms")
+        if waveforms.dim() == 3:
+            assert waveforms.shape[1] == 1, f"Only single channel is supported. You have {waveforms.shape[1]}"
+            waveforms = waveforms[:, 0, :]
+        return self.runtime(waveforms.device).forward_wav(waveforms, want_logits=want_logits)
+
+    def forward_waveform(self, pcm: torch.Tensor):
+        return self.forward_logits(pcm)
+
+    def attach_fbank(self, config):
+        raise RuntimeError("PyanNet consumes raw waveforms (SincNet); log-mel features belong to PyanNet2")

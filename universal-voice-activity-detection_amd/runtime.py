@@ -18,8 +18,9 @@ def _model_cfg(encoding_dim: int, lstm: dict, linear: dict, leaky_slope: float =
 
 
 class VadRuntime:
-    def __init__(self, device, fbank: Optional[FbankConfig] = None, model: Optional[dict] = None):
-        """model: {"encoding_dim": int, "lstm": {...merged defaults...}, "linear": {...}} or None."""
+    def __init__(self, device, fbank: Optional[FbankConfig] = None, model: Optional[dict] = None, sincnet: Optional[dict] = None):
+        """model: {"encoding_dim": int, "lstm": {...merged defaults...}, "linear": {...}} or None.
+        sincnet: SincNet.config() (stride, n_filters, kernel_size, c2, k2, c3, k3, leaky_slope, eps) or None."""
         self.lib = _lib.load()
         dev = torch.device(device)
         if dev.type != "cuda":
@@ -54,6 +55,16 @@ class VadRuntime:
             self.set_tables(win, mel)
         self._ws = None
         self._finalized = False
+        self._sn_c = None
+        if sincnet is not None:
+            self._sn_c = _lib.SincNetCfg(int(sincnet["stride"]), int(sincnet["n_filters"]), int(sincnet["kernel_size"]),
+                                         int(sincnet["c2"]), int(sincnet["k2"]), int(sincnet["c3"]), int(sincnet["k3"]),
+                                         float(sincnet.get("leaky_slope", 0.01)), float(sincnet.get("eps", 1e-5)))
+            try:
+                self._check(self.lib.uvad_sincnet_configure(self.ctx, C.byref(self._sn_c)))
+            except Exception:
+                self.close()
+                raise
 
     # ------------------------------------------------------------------ setup
     def set_tables(self, window: np.ndarray, mel: np.ndarray):
@@ -66,6 +77,8 @@ class VadRuntime:
     def load_state_dict(self, sd: Dict[str, "torch.Tensor"]):
         """torch-keyed tensors (CPU or GPU; a Lightning ``model.`` prefix is accepted)."""
         for k, v in sd.items():
+            if ".filterbank." in k:
+                continue   # band edges / buffers of ParamSincFB: the materialised bank is sent as "...conv1d.0.filters"
             a = np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy() if torch.is_tensor(v) else v, np.float32)
             shape = (C.c_int64 * a.ndim)(*a.shape)
             self._check(self.lib.uvad_set_weight(self.ctx, k.encode(), a.ctypes.data, shape, a.ndim))
@@ -144,6 +157,54 @@ class VadRuntime:
                                               logits.data_ptr() if want_logits else None,
                                               probs.data_ptr() if want_probs else None,
                                               ws.data_ptr(), ws.numel(), self._stream()))
+            self._last_bt = (B, T)
+            return logits, probs
+
+    # ------------------------------------------------------------------ SincNet front end (PyanNet)
+    def sincnet_num_frames(self, S: int) -> int:
+        return int(self.lib.uvad_sincnet_num_frames(self.ctx, S))
+
+    def _wav_ws(self, B: int, S: int, T: int, with_classifier: bool) -> "torch.Tensor":
+        need = int(self.lib.uvad_sincnet_workspace_bytes(self.ctx, B, S))
+        if with_classifier:
+            need += int(self.lib.uvad_workspace_bytes(self.ctx, B, T))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def sincnet(self, wav: "torch.Tensor") -> "torch.Tensor":
+        """wav (B,S) f32 on the GPU -> SincNet features (B, frames, c3)."""
+        if self._sn_c is None:
+            raise RuntimeError("this runtime was created without a SincNet configuration")
+        with torch.cuda.device(self.device):
+            wav = self._dev_f32(wav, "wav")
+            B, S = wav.shape
+            T = self.sincnet_num_frames(S)
+            if T <= 0:
+                raise ValueError(f"{S} samples are too short for one SincNet frame")
+            ws = self._wav_ws(B, S, T, False)
+            feats = torch.empty((B, T, self._sn_c.c3), dtype=torch.float32, device=self.device)
+            self._check(self.lib.uvad_sincnet(self.ctx, wav.data_ptr(), B, S, feats.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+            return feats
+
+    def forward_wav(self, wav: "torch.Tensor", want_logits=True, want_probs=True):
+        """wav (B,S) f32 on the GPU -> (logits, probs) of PyanNet (SincNet -> LSTM stack -> head)."""
+        if self._sn_c is None:
+            raise RuntimeError("this runtime was created without a SincNet configuration")
+        with torch.cuda.device(self.device):
+            wav = self._dev_f32(wav, "wav")
+            B, S = wav.shape
+            T = self.sincnet_num_frames(S)
+            if T <= 0:
+                raise ValueError(f"{S} samples are too short for one SincNet frame")
+            ws = self._wav_ws(B, S, T, True)
+            logits = torch.empty((B, T), dtype=torch.float32, device=self.device) if want_logits else None
+            probs = torch.empty((B, T), dtype=torch.float32, device=self.device) if want_probs else None
+            self._check(self.lib.uvad_forward_wav(self.ctx, wav.data_ptr(), B, S,
+                                                  logits.data_ptr() if want_logits else None,
+                                                  probs.data_ptr() if want_probs else None,
+                                                  ws.data_ptr(), ws.numel(), self._stream()))
             self._last_bt = (B, T)
             return logits, probs
 
