@@ -44,7 +44,7 @@ def _pair(seed=99, lstm=None):
     return front, cls.eval(), m.to("cuda:0").eval()
 
 
-@pytest.mark.parametrize("B,S", [(3, 32000 + 37), (1, 80000), (5, 4000), (2, 1000)])
+@pytest.mark.parametrize("B,S", [(3, 32000 + 37), (1, 80000), (5, 4000), (2, 1300)])
 def test_sincnet_features_match_oracle(B, S):
     from oracle import torch_ref as tr
     front, _, m = _pair()

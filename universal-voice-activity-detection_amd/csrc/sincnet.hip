@@ -15,7 +15,7 @@
 // x all output channels; the whole transposed filter matrix ([K/2][N][2] so that one ds_read_b32 per lane
 // feeds the B operand without bank conflicts) stays in LDS across the tiles a workgroup walks, the input
 // window is staged with the previous layer's normalisation + leaky_relu folded in, and the epilogue does
-// bias, |.|, the 3:1 max pool and the per-tile (sum, sum of squares) the instance norm of the next stage
+// bias, |.|, the 3:1 max pool and the per-tile (sum, M2) statistics the instance norm of the next stage
 // needs -- written as per-tile partials and reduced in tile order, so results do not depend on scheduling.
 #include "uvad_internal.h"
 
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(192) void conv_pool_kernel(SincConvArgs a) {
     const int li = lane & 31, kk = lane >> 5;
     const int b = blockIdx.y;
     const int XW = (CT - 1) * a.stride + a.Kw;
-    const int rows = a.Cin + (a.Ktot & 1);             // one zero row when the padded K reads past the last channel
+    const int rows = a.Cin + (a.Kp > a.Ktot);          // one zero row when the padded K reads past the last channel
 
     {   // filter matrix -> LDS once per workgroup (float4; Kp*NW is a multiple of 64)
         const float4 *src = reinterpret_cast<const float4 *>(a.Wt2);
@@ -101,26 +101,44 @@ __global__ __launch_bounds__(192) void conv_pool_kernel(SincConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+        // K loop, software pipelined over two register sets: the operands of step ks+1 are read from LDS
+        // before the MFMAs of step ks are issued (sched_group_barrier pins that order), so the ~100-cycle LDS
+        // latency hides under the 64-cycle MFMAs instead of between them.  Kp is a multiple of 4 => ksteps even.
         const float *bp = wt + (size_t)li * 2 + kk;
         int aoff = (wave * 32 + li) * a.stride + kk;
         int kw = kk;
         const int ksteps = a.Kp >> 1;
-#pragma unroll 4
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const float av = xy[aoff];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float bv = bp[(size_t)ks * (NW * 2) + t * 64];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-            }
-            if (CIN1) {
-                aoff += 2;
-            } else {
-                kw += 2;
-                aoff += 2;
-                if (kw >= a.Kw) { kw -= a.Kw; aoff += XW - a.Kw; }
-            }
+        float a0, a1, b0[NT], b1[NT];
+#define UVAD_SN_LOAD(AV, BV, ks_)                                                          \
+    {                                                                                      \
+        AV = xy[aoff];                                                                     \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) BV[t] = bp[(size_t)(ks_) * (NW * 2) + t * 64]; \
+        if (CIN1) {                                                                        \
+            aoff += 2;                                                                     \
+        } else {                                                                           \
+            kw += 2;                                                                       \
+            aoff += 2;                                                                     \
+            if (kw >= a.Kw) { kw -= a.Kw; aoff += XW - a.Kw; }                             \
+        }                                                                                  \
+    }
+#define UVAD_SN_MFMA(AV, BV) \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV[t], acc[t], 0, 0, 0);
+        UVAD_SN_LOAD(a0, b0, 0)
+        for (int ks = 0; ks + 2 < ksteps; ks += 2) {
+            UVAD_SN_LOAD(a1, b1, ks + 1)
+            UVAD_SN_MFMA(a0, b0)
+            UVAD_SN_LOAD(a0, b0, ks + 2)
+            UVAD_SN_MFMA(a1, b1)
+            __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);   // DS reads of set 1
+            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);       // MFMAs of set 0
+            __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);   // DS reads of set 0 (next pair)
+            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);       // MFMAs of set 1
         }
+        UVAD_SN_LOAD(a1, b1, ksteps - 1)
+        UVAD_SN_MFMA(a0, b0)
+        UVAD_SN_MFMA(a1, b1)
+#undef UVAD_SN_LOAD
+#undef UVAD_SN_MFMA
         __syncthreads();   // all A reads of the input window are done: the region becomes the output tile
 
 #pragma unroll
@@ -144,33 +162,41 @@ __global__ __launch_bounds__(192) void conv_pool_kernel(SincConvArgs a) {
             const float m = __builtin_fmaxf(__builtin_fmaxf(y[0], y[1]), y[2]);
             const bool valid = n < a.Cout && p0 + p < a.Lpool;
             if (valid) a.out[((size_t)b * a.Cout + n) * a.Lpool + p0 + p] = m;
-            float s = valid ? m : 0.f, ss = s * s;
+            // per-tile (sum, M2 about the tile mean): combined in tile order by norm_finalize_kernel (Chan's
+            // update), which keeps the variance accurate when it is small against the mean (short inputs)
+            float s = valid ? m : 0.f;
 #pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+            for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+            const int nt = a.Lpool - p0 < 32 ? a.Lpool - p0 : 32;
+            const float d = valid ? m - s / (float)nt : 0.f;
+            float m2 = d * d;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) m2 += __shfl_xor(m2, o);
             if (p == 0) {
                 float *pp = a.partials + (((size_t)b * a.ntiles + tile) * NW + n) * 2;
                 pp[0] = s;
-                pp[1] = ss;
+                pp[1] = m2;
             }
         }
     }
 }
 
-// (sum, sum of squares) partials in tile order -> per (b, c) affine of the instance norm:
+// per-tile (sum, M2) partials, combined in tile order -> per (b, c) affine of the instance norm:
 //   y = (x - mean) / sqrt(var + eps) * gamma + beta = x * scale + shift      (biased variance, torch InstanceNorm1d)
 __global__ __launch_bounds__(128) void norm_finalize_kernel(const float *partials, int ntiles, int NW, int C, int L, const float *gamma,
                                                             const float *beta, float eps, float *scale, float *shift) {
     const int b = blockIdx.x, n = threadIdx.x;
     if (n >= C) return;
-    double s = 0.0, ss = 0.0;
+    double mean = 0.0, M2 = 0.0, cnt = 0.0;
     for (int t = 0; t < ntiles; ++t) {
         const float *pp = partials + (((size_t)b * ntiles + t) * NW + n) * 2;
-        s += (double)pp[0];
-        ss += (double)pp[1];
+        const double nt = (double)(L - 32 * t < 32 ? L - 32 * t : 32);
+        const double mt = (double)pp[0] / nt, delta = mt - mean, tot = cnt + nt;
+        M2 += (double)pp[1] + delta * delta * cnt * nt / tot;
+        mean += delta * nt / tot;
+        cnt = tot;
     }
-    const double mean = s / (double)L;
-    double var = ss / (double)L - mean * mean;
-    if (var < 0.0) var = 0.0;
+    const double var = M2 / (double)L;
     const double sc = (double)gamma[n] / sqrt(var + (double)eps);
     scale[(size_t)b * C + n] = (float)sc;
     shift[(size_t)b * C + n] = (float)((double)beta[n] - mean * sc);
@@ -195,7 +221,7 @@ __global__ __launch_bounds__(256) void sinc_out_kernel(const float *P, const flo
 size_t sinc_conv_lds_bytes(const SincConvArgs &a, int NT) {
     const int NW = NT * 32;
     const int XW = (CT - 1) * a.stride + a.Kw;
-    const size_t rows = (size_t)a.Cin + (a.Ktot & 1);
+    const size_t rows = (size_t)a.Cin + (a.Kp > a.Ktot);
     size_t xy = rows * XW + 8;
     if (xy < (size_t)NW * YS) xy = (size_t)NW * YS;
     return ((size_t)a.Kp * NW + xy) * sizeof(float);

@@ -392,7 +392,7 @@ int uvad_finalize(uvad_ctx *c) {
             if (!wshape || (b && !expect_shape(*b, {cout[i]})) || !expect_shape(*g, {cout[i]}) || !expect_shape(*be, {cout[i]}))
                 return fail(c, UVAD_E_ARG, "sincnet stage " + id + " tensor shape mismatch");
             // W[n][k = ci*Kw + kw] -> [Kp/2][NW][2], zero padded in n and k (sincnet.hip B-operand layout)
-            const int Ktot = cin[i] * kw[i], Kp = (Ktot + 1) / 2 * 2, NW = (cout[i] + 31) / 32 * 32;
+            const int Ktot = cin[i] * kw[i], Kp = (Ktot + 3) / 4 * 4, NW = (cout[i] + 31) / 32 * 32;
             std::vector<float> wt((size_t)Kp * NW, 0.0f), bias((size_t)NW, 0.0f);
             for (int n = 0; n < cout[i]; ++n) {
                 for (int k = 0; k < Ktot; ++k) wt[((size_t)(k >> 1) * NW + n) * 2 + (k & 1)] = w->data[(size_t)n * Ktot + k];
@@ -412,7 +412,7 @@ int uvad_finalize(uvad_ctx *c) {
 int uvad_sincnet_configure(uvad_ctx *c, const uvad_sincnet_cfg *q) {
     if (!c || !q) return UVAD_E_ARG;
     if (!c->has_model) return fail(c, UVAD_E_STATE, "uvad_sincnet_configure: context was created without a model configuration");
-    if (q->stride < 1 || q->kernel_size < 2 || q->k2 < 2 || q->k3 < 2 || q->n_filters < 1 || q->c2 < 1 || q->c3 < 1)
+    if (q->stride < 1 || q->kernel_size < 3 || q->k2 < 3 || q->k3 < 3 || q->n_filters < 1 || q->c2 < 1 || q->c3 < 1)
         return fail(c, UVAD_E_ARG, "bad SincNet configuration");
     const int cout[3] = {q->n_filters, q->c2, q->c3};
     for (int i = 0; i < 3; ++i)
@@ -422,7 +422,7 @@ int uvad_sincnet_configure(uvad_ctx *c, const uvad_sincnet_cfg *q) {
     const int cin[3] = {1, q->n_filters, q->c2}, kw[3] = {q->kernel_size, q->k2, q->k3};
     for (int i = 0; i < 3; ++i) {
         SincConvArgs a{};
-        a.Cin = cin[i]; a.Kw = kw[i]; a.stride = i == 0 ? q->stride : 1; a.Ktot = cin[i] * kw[i]; a.Kp = (a.Ktot + 1) / 2 * 2;
+        a.Cin = cin[i]; a.Kw = kw[i]; a.stride = i == 0 ? q->stride : 1; a.Ktot = cin[i] * kw[i]; a.Kp = (a.Ktot + 3) / 4 * 4;
         if (sinc_conv_lds_bytes(a, (cout[i] + 31) / 32) > (size_t)160 * 1024)
             return fail(c, UVAD_E_UNSUPPORTED, "SincNet stage does not fit the 160 KiB LDS (filter matrix is LDS-resident)");
     }
@@ -465,7 +465,7 @@ static int sincnet_impl(uvad_ctx *c, const float *d_wav, int B, int64_t S, float
         a.in = in; a.in_bstride = (long long)l.Cin[i] * l.Lin[i]; a.Cin = l.Cin[i]; a.Lin = (int)l.Lin[i];
         a.in_scale = in_scale; a.in_shift = in_shift; a.in_lrelu = i > 0; a.slope = q.leaky_slope;
         a.Wt2 = c->sn_wt[i]; a.bias = c->sn_bias[i];
-        a.Kw = l.Kw[i]; a.stride = l.stride[i]; a.Ktot = l.Cin[i] * l.Kw[i]; a.Kp = (a.Ktot + 1) / 2 * 2; a.Cout = l.Cout[i]; a.do_abs = i == 0;
+        a.Kw = l.Kw[i]; a.stride = l.stride[i]; a.Ktot = l.Cin[i] * l.Kw[i]; a.Kp = (a.Ktot + 3) / 4 * 4; a.Cout = l.Cout[i]; a.do_abs = i == 0;
         a.Lconv = (int)l.Lconv[i]; a.Lpool = (int)l.Lpool[i]; a.ntiles = l.ntiles[i];
         a.out = P; a.partials = part; a.B = B;
         HIPCHK(c, launch_sinc_conv(a, s));

@@ -114,10 +114,10 @@ struct SincConvArgs {
     int in_lrelu; float slope;                             // then leaky_relu (layers after the first)
     const float *Wt2;                                      // [Kp/2][NW][2]: W[n][k = 2*ks + kk] transposed, zero padded (NW = 32*ceil(Cout/32))
     const float *bias;                                     // [NW] zero padded
-    int Kw, stride, Ktot, Kp, Cout, do_abs;                // Ktot = Cin*Kw, Kp = Ktot rounded up to even
+    int Kw, stride, Ktot, Kp, Cout, do_abs;                // Ktot = Cin*Kw, Kp = Ktot rounded up to a multiple of 4
     int Lconv, Lpool, ntiles;                              // ntiles = ceil(Lpool / 32)
     float *out;                                            // [B][Cout][Lpool] pooled, before the norm
-    float *partials;                                       // [B][ntiles][NW][2] (sum, sum of squares) of the pooled tile
+    float *partials;                                       // [B][ntiles][NW][2] (sum, M2 about the tile mean) of the pooled tile
     int B;
 };
 hipError_t launch_wav_stats(const float *wav, int B, long long S, long long row_stride, const float *gamma, const float *beta, float eps,

@@ -53,6 +53,8 @@ def seed_weights(model: torch.nn.Module, seed: int = 1234, scale: float = 4.0) -
     g = torch.Generator().manual_seed(seed)
     hidden = model.hparams.lstm["hidden_size"] if hasattr(model, "hparams") else 128
     for k, v in model.state_dict().items():
+        if k.startswith("sincnet."):
+            continue   # the SincNet front end of a PyanNet keeps its own (mel-spaced / affine-identity) initialisation
         if k.startswith("lstm"):
             bound = 1.0 / math.sqrt(hidden)
         else:
