@@ -12,9 +12,10 @@
 //
 // The convolutions are implicit GEMMs on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32 products and
 // a k-ordered accumulation): a workgroup of 3 waves owns 96 consecutive conv positions (= 32 pooled outputs)
-// x all output channels; the whole transposed filter matrix ([K/2][N][2] so that one ds_read_b32 per lane
-// feeds the B operand without bank conflicts) stays in LDS across the tiles a workgroup walks, the input
-// window is staged with the previous layer's normalisation + leaky_relu folded in, and the epilogue does
+// x all output channels; the whole transposed filter matrix ([K][N]: one conflict-free ds_read_b32 per lane
+// feeds the B operand) stays in LDS across the tiles a workgroup walks; the input window of the NEXT tile is
+// fetched into registers while the matrix cores work on the current one and is written to LDS with the
+// previous layer's normalisation + leaky_relu folded in; the epilogue does
 // bias, |.|, the 3:1 max pool and the per-tile (sum, M2) statistics the instance norm of the next stage
 // needs -- written as per-tile partials and reduced in tile order, so results do not depend on scheduling.
 #include "uvad_internal.h"
@@ -24,6 +25,21 @@ namespace uvad {
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// Sum over each 32-lane half of the wave, returned in every lane of the half (DPP adds inside the 16-lane rows,
+// row_bcast:15 into the odd rows, then the totals sit in lanes 31 and 63).  Inactive half-waves read as zero.
+#define UVAD_SN_DPP_ADD(V, CTRL, ROW_MASK) \
+    V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, ROW_MASK, 0xF, true))
+__device__ __forceinline__ float half_sum(float v, bool upper) {
+    UVAD_SN_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
+    UVAD_SN_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
+    UVAD_SN_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror
+    UVAD_SN_DPP_ADD(v, 0x140, 0xF);   // row_mirror: every lane holds its row total
+    UVAD_SN_DPP_ADD(v, 0x142, 0xA);   // row_bcast:15 into rows 1 and 3
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    return upper ? hi : lo;
+}
 
 constexpr int CT = 96;        // conv positions per tile (3 waves x 32 MFMA rows) = 32 pooled outputs
 constexpr int YS = 97;        // LDS row stride of the conv-output staging tile
@@ -55,45 +71,109 @@ __global__ __launch_bounds__(256) void wav_stats_kernel(const float *wav, long l
     }
 }
 
-template <int NT, bool CIN1>
+template <int NT, bool CIN1, int EPT>
 __global__ __launch_bounds__(192) void conv_pool_kernel(SincConvArgs a) {
     constexpr int NW = NT * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *wt = smem;                                  // [Kp/2][NW][2]
-    float *xy = smem + (size_t)a.Kp * NW;              // input window [rows][XW] / conv-output tile [NW][YS]
+    // (scale, shift) of the current utterance's input norm: a separate LDS object, so the compiler knows the window
+    // stores below cannot alias it (with one array every store waited for the previous (scale, shift) read)
+    __shared__ float2 nrm[96];
+    float *wt = smem;                                  // [Kp][NW]: W^T, zero padded
+    float *xy = smem + (size_t)a.Kp * NW;              // input window [Cin][XW] (+ zero pad, + 1 dump slot) / conv-output tile [NW][YS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kk = lane >> 5;
-    const int b = blockIdx.y;
     const int XW = (CT - 1) * a.stride + a.Kw;
-    const int rows = a.Cin + (a.Kp > a.Ktot);          // one zero row when the padded K reads past the last channel
+    const int nelem = a.Cin * XW;                      // real elements of the window
+    const int npad = 8;                                // the Kp - Ktot <= 7 zero-weight padded k read taps >= Kw: <= 7 elements past the window
+    const int dump = nelem + npad;                     // where the staging stores of threads past the window go
 
-    {   // filter matrix -> LDS once per workgroup (float4; Kp*NW is a multiple of 64)
+    // Persistent workgroups (one per CU: the filter matrix takes most of the LDS): workgroup w owns the contiguous
+    // range [g_begin, g_end) of the B*ntiles (utterance, tile) pairs, so the filter matrix is staged once per launch.
+    const long long total = (long long)a.B * a.ntiles;
+    const long long per = (total + gridDim.x - 1) / gridDim.x;
+    const long long g_begin = per * blockIdx.x;
+    const long long g_end = g_begin + per < total ? g_begin + per : total;
+    if (g_begin >= g_end) return;
+
+    {   // filter matrix -> LDS (Kp*NW is a multiple of 128 floats), 8 independent 16-byte loads in flight per thread
         const float4 *src = reinterpret_cast<const float4 *>(a.Wt2);
         float4 *dst = reinterpret_cast<float4 *>(wt);
         const int n4 = a.Kp * NW / 4;
-        for (int i = tid; i < n4; i += 192) dst[i] = src[i];
+        for (int i0 = 0; i0 < n4; i0 += 192 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int i = i0 + j * 192 + tid; v[j] = src[i < n4 ? i : 0]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int i = i0 + j * 192 + tid; if (i < n4) dst[i] = v[j]; }
+        }
     }
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const int c0 = tile * CT;
-        const long long x0 = (long long)c0 * a.stride;
-        __syncthreads();   // weights staged / previous tile's pooled reads of xy are complete
-        for (int ci = wave; ci < rows; ci += 3) {
-            const bool real = ci < a.Cin;
-            const float sc = real ? a.in_scale[(size_t)b * a.Cin + ci] : 0.f;
-            const float sh = real ? a.in_shift[(size_t)b * a.Cin + ci] : 0.f;
-            const float *src = a.in + (size_t)b * a.in_bstride + (size_t)(real ? ci : 0) * a.Lin;
-            for (int x = lane; x < XW + 1; x += 64) {
-                const long long gx = x0 + x;
-                float v = 0.f;
-                if (real && x < XW && gx < a.Lin) {
-                    v = __builtin_fmaf(src[gx], sc, sh);
-                    if (a.in_lrelu) v = v >= 0.f ? v : v * a.slope;
-                }
-                if (x < XW || ci == rows - 1) xy[(size_t)ci * XW + x] = v;   // the one-past element exists only after the last row
-            }
+    // Window element e of this thread is linear index idx = tid + 192*e of [Cin][XW] -> (ci, x), walked incrementally.
+    const int ci0 = tid / XW, xs0 = tid - ci0 * XW;
+    const int qstep = 192 / XW, rstep = 192 - qstep * XW;
+    float pre[EPT];
+#define UVAD_SN_PREFETCH(g_)                                                               \
+    {   /* 32-bit element offsets from the utterance's (wave-uniform) base: one address VGPR per load */ \
+        const int b_ = (int)((g_) / a.ntiles), tile_ = (int)((g_) - (long long)b_ * a.ntiles); \
+        const float *inb_ = a.in + (size_t)b_ * a.in_bstride;                              \
+        const int x0_ = tile_ * CT * a.stride;                                             \
+        int x_ = xs0;                                                                      \
+        unsigned off_ = (unsigned)ci0 * (unsigned)a.Lin + (unsigned)(x0_ + xs0);           \
+        _Pragma("unroll") for (int e = 0; e < EPT; ++e) {                                  \
+            const bool ok_ = tid + 192 * e < nelem && x0_ + x_ < a.Lin;                    \
+            pre[e] = inb_[ok_ ? off_ : 0u];                                                \
+            x_ += rstep; off_ += (unsigned)qstep * (unsigned)a.Lin + (unsigned)rstep;      \
+            if (x_ >= XW) { x_ -= XW; off_ += (unsigned)(a.Lin - XW); }                    \
+        }                                                                                  \
+    }
+#ifdef UVAD_SN_ABL_NOSTAGE   // diagnostic builds (tools/sinc_ablate.hip): no input staging at all
+#undef UVAD_SN_PREFETCH
+#define UVAD_SN_PREFETCH(g_) {}
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) pre[e] = 0.f;
+#endif
+    UVAD_SN_PREFETCH(g_begin)
+
+    int cur_b = -1;
+    for (long long g = g_begin; g < g_end; ++g) {
+        const int b = (int)(g / a.ntiles), tile = (int)(g - (long long)b * a.ntiles);
+        __syncthreads();   // filter matrix staged / previous tile's pooled reads of xy are complete
+        if (b != cur_b) {  // (scale, shift) of this utterance's input norm
+            cur_b = b;
+            if (tid < a.Cin) nrm[tid] = make_float2(a.in_scale[(size_t)b * a.Cin + tid], a.in_shift[(size_t)b * a.Cin + tid]);
+            __syncthreads();
         }
+#ifndef UVAD_SN_ABL_NOSTAGE
+        {   // registers -> LDS with the previous stage's instance norm (+ leaky_relu) folded in; branch-free: threads
+            // past the window store into a dump slot
+            const int x0 = tile * CT * a.stride;
+            int ci = ci0, x = xs0;
+#pragma unroll
+            for (int e0 = 0; e0 < EPT; e0 += 8) {   // eight (scale, shift) reads in flight, then eight stores
+                float2 ns[8];
+                bool in[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    ns[j] = nrm[ci < a.Cin ? ci : 0];
+                    in[j] = x0 + x < a.Lin;
+                    ci += qstep; x += rstep;
+                    if (x >= XW) { x -= XW; ++ci; }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the eight reads together (the scheduler pairs them otherwise)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int idx = tid + 192 * (e0 + j);
+                    float v = __builtin_fmaf(pre[e0 + j], ns[j].x, ns[j].y);
+                    if (a.in_lrelu) v = v >= 0.f ? v : v * a.slope;
+                    xy[idx < nelem ? idx : dump] = in[j] ? v : 0.f;
+                }
+            }
+            for (int i = tid; i < npad; i += 192) xy[nelem + i] = 0.f;   // what the zero-weight padded K steps read
+        }
+#endif
         __syncthreads();
+        // the next tile's window is fetched now and lands while the matrix cores work on this one
+        if (g + 1 < g_end) UVAD_SN_PREFETCH(g + 1)
 
         f32x16 acc[NT];
 #pragma unroll
@@ -101,46 +181,74 @@ __global__ __launch_bounds__(192) void conv_pool_kernel(SincConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-        // K loop, software pipelined over two register sets: the operands of step ks+1 are read from LDS
-        // before the MFMAs of step ks are issued (sched_group_barrier pins that order), so the ~100-cycle LDS
-        // latency hides under the 64-cycle MFMAs instead of between them.  Kp is a multiple of 4 => ksteps even.
-        const float *bp = wt + (size_t)li * 2 + kk;
-        int aoff = (wave * 32 + li) * a.stride + kk;
-        int kw = kk;
+        // K loop, software pipelined over four register sets: the operands of step ks+2 are read from LDS
+        // before the MFMAs of step ks are issued (sched_group_barrier pins that order), i.e. every ds_read has
+        // 2*NT MFMAs (256 / 384 cycles) to land.  Kp is a multiple of 8 => ksteps is a multiple of 4.
+        // K order: single-channel stage k = tap; multi-channel stages k = tap*Cin + channel (channel-minor, Cin even), so
+        // the two lane halves (k, k+1) are two channels at one tap and the walk through the window is wave-uniform:
+        // soff is scalar arithmetic, no per-lane wrap logic between the MFMAs (that cost 25 % of the K loop).
+        const float *bp = wt + (size_t)kk * NW + li;
+        const int abase = (wave * 32 + li) * a.stride + (CIN1 ? kk : kk * XW);
+        int soff = 0, cpair = 0;
+        const int chalf = a.Cin >> 1;
+#ifdef UVAD_SN_ABL_NOK      // diagnostic builds: what the tile costs without the K loop
+        const int ksteps = 4;
+#else
         const int ksteps = a.Kp >> 1;
-        float a0, a1, b0[NT], b1[NT];
+#endif
+        float a0, a1, a2, a3, b0[NT], b1[NT], b2[NT], b3[NT];
 #define UVAD_SN_LOAD(AV, BV, ks_)                                                          \
     {                                                                                      \
-        AV = xy[aoff];                                                                     \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) BV[t] = bp[(size_t)(ks_) * (NW * 2) + t * 64]; \
+        AV = xy[abase + soff];                                                             \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) BV[t] = bp[(size_t)(ks_) * (NW * 2) + t * 32]; \
         if (CIN1) {                                                                        \
-            aoff += 2;                                                                     \
+            soff += 2;                                                                     \
         } else {                                                                           \
-            kw += 2;                                                                       \
-            aoff += 2;                                                                     \
-            if (kw >= a.Kw) { kw -= a.Kw; aoff += XW - a.Kw; }                             \
+            soff += 2 * XW;                                                                \
+            if (++cpair == chalf) { cpair = 0; soff += 1 - a.Cin * XW; }                   \
         }                                                                                  \
     }
 #define UVAD_SN_MFMA(AV, BV) \
     _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV[t], acc[t], 0, 0, 0);
+#define UVAD_SN_GROUPS()                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0); /* DS reads */ \
+    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);     /* MFMAs    */
         UVAD_SN_LOAD(a0, b0, 0)
-        for (int ks = 0; ks + 2 < ksteps; ks += 2) {
-            UVAD_SN_LOAD(a1, b1, ks + 1)
+        UVAD_SN_LOAD(a1, b1, 1)
+        int ks = 0;
+        for (; ks + 4 < ksteps; ks += 4) {
+            UVAD_SN_LOAD(a2, b2, ks + 2)
             UVAD_SN_MFMA(a0, b0)
-            UVAD_SN_LOAD(a0, b0, ks + 2)
+            UVAD_SN_LOAD(a3, b3, ks + 3)
             UVAD_SN_MFMA(a1, b1)
-            __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);   // DS reads of set 1
-            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);       // MFMAs of set 0
-            __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);   // DS reads of set 0 (next pair)
-            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);       // MFMAs of set 1
+            UVAD_SN_LOAD(a0, b0, ks + 4)
+            UVAD_SN_MFMA(a2, b2)
+            UVAD_SN_LOAD(a1, b1, ks + 5)
+            UVAD_SN_MFMA(a3, b3)
+            UVAD_SN_GROUPS() UVAD_SN_GROUPS() UVAD_SN_GROUPS() UVAD_SN_GROUPS()
         }
-        UVAD_SN_LOAD(a1, b1, ksteps - 1)
+        UVAD_SN_LOAD(a2, b2, ks + 2)
         UVAD_SN_MFMA(a0, b0)
+        UVAD_SN_LOAD(a3, b3, ks + 3)
         UVAD_SN_MFMA(a1, b1)
+        UVAD_SN_MFMA(a2, b2)
+        UVAD_SN_MFMA(a3, b3)
+#undef UVAD_SN_GROUPS
 #undef UVAD_SN_LOAD
 #undef UVAD_SN_MFMA
         __syncthreads();   // all A reads of the input window are done: the region becomes the output tile
 
+#ifdef UVAD_SN_ABL_NOEPI    // diagnostic: no epilogue (the accumulators stay live through a never-taken store)
+        {
+            float chk = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) chk += acc[t][r];
+            if (chk == 12345.678f) a.out[tid] = chk;
+            continue;
+        }
+#endif
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int n = t * 32 + li;
@@ -155,24 +263,25 @@ __global__ __launch_bounds__(192) void conv_pool_kernel(SincConvArgs a) {
         }
         __syncthreads();
 
+        // 3:1 max pool, store, and the tile's (sum, M2 about the tile mean) per channel -- combined in tile order by
+        // norm_finalize_kernel (Chan's update), which keeps the variance accurate when it is small against the mean.
+        // Each 32-lane half owns one channel per pass; unrolled x4 so the passes' LDS reads and DPP chains overlap.
         const int p0 = tile * (CT / 3);
-        for (int idx = tid; idx < NW * 32; idx += 192) {
-            const int n = idx >> 5, p = idx & 31;
-            const float *y = xy + (size_t)n * YS + 3 * p;
+        const int nt = a.Lpool - p0 < 32 ? a.Lpool - p0 : 32;
+        const float inv_nt = 1.0f / (float)nt;
+        constexpr int PASSES = (NW + 5) / 6;
+#pragma unroll 4
+        for (int j = 0; j < PASSES; ++j) {
+            const int n = j * 6 + wave * 2 + kk, p = li;
+            const int nc = n < NW ? n : NW - 1;
+            const float *y = xy + (size_t)nc * YS + 3 * p;
             const float m = __builtin_fmaxf(__builtin_fmaxf(y[0], y[1]), y[2]);
-            const bool valid = n < a.Cout && p0 + p < a.Lpool;
+            const bool valid = n < a.Cout && p < nt;
             if (valid) a.out[((size_t)b * a.Cout + n) * a.Lpool + p0 + p] = m;
-            // per-tile (sum, M2 about the tile mean): combined in tile order by norm_finalize_kernel (Chan's
-            // update), which keeps the variance accurate when it is small against the mean (short inputs)
-            float s = valid ? m : 0.f;
-#pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-            const int nt = a.Lpool - p0 < 32 ? a.Lpool - p0 : 32;
-            const float d = valid ? m - s / (float)nt : 0.f;
-            float m2 = d * d;
-#pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) m2 += __shfl_xor(m2, o);
-            if (p == 0) {
+            const float s = half_sum(valid ? m : 0.f, kk != 0);
+            const float d = valid ? m - s * inv_nt : 0.f;
+            const float m2 = half_sum(d * d, kk != 0);
+            if (p == 0 && n < NW) {
                 float *pp = a.partials + (((size_t)b * a.ntiles + tile) * NW + n) * 2;
                 pp[0] = s;
                 pp[1] = m2;
@@ -221,10 +330,15 @@ __global__ __launch_bounds__(256) void sinc_out_kernel(const float *P, const flo
 size_t sinc_conv_lds_bytes(const SincConvArgs &a, int NT) {
     const int NW = NT * 32;
     const int XW = (CT - 1) * a.stride + a.Kw;
-    const size_t rows = (size_t)a.Cin + (a.Kp > a.Ktot);
-    size_t xy = rows * XW + 8;
+    size_t xy = (size_t)a.Cin * XW + 8 + 1;
     if (xy < (size_t)NW * YS) xy = (size_t)NW * YS;
-    return ((size_t)a.Kp * NW + xy) * sizeof(float);
+    return ((size_t)a.Kp * NW + xy) * sizeof(float) + 96 * sizeof(float2);   // + the static (scale, shift) table
+}
+
+// elements of the input window each of the 192 threads carries in registers between tiles
+int sinc_conv_ept(const SincConvArgs &a) {
+    const int XW = (CT - 1) * a.stride + a.Kw;
+    return (a.Cin * XW + 191) / 192;
 }
 
 hipError_t launch_wav_stats(const float *wav, int B, long long S, long long row_stride, const float *gamma, const float *beta, float eps,
@@ -237,24 +351,28 @@ hipError_t launch_sinc_conv(const SincConvArgs &a, hipStream_t s) {
     const int NT = (a.Cout + 31) / 32;
     if (NT != 2 && NT != 3) return hipErrorInvalidValue;
     const size_t lds = sinc_conv_lds_bytes(a, NT);
-    // enough workgroups to fill 256 CUs (one per CU: the filter matrix takes most of the LDS), each walking
-    // several tiles of one utterance so the filter matrix is staged once per walk
-    int gx = (1024 + a.B - 1) / a.B;
-    if (gx > a.ntiles) gx = a.ntiles;
-    if (gx < 1) gx = 1;
-    const dim3 grid(gx, a.B), block(192);
+    // persistent workgroups, one per CU (the LDS-resident filter matrix allows no more), each walking a contiguous
+    // range of the (utterance, tile) pairs
+    const long long total = (long long)a.B * a.ntiles;
+    const int ncu = a.n_cu > 0 ? a.n_cu : 256;
+    const dim3 grid((unsigned)(total < ncu ? total : ncu)), block(192);
     const bool cin1 = a.Cin == 1;
-#define UVAD_SINC_LAUNCH(NT_, C1_)                                                                                         \
+    const int ept = sinc_conv_ept(a);
+    if (ept > 48 || (cin1 && ept > 8)) return hipErrorInvalidValue;   // uvad_sincnet_configure rejects these geometries
+#define UVAD_SINC_LAUNCH(NT_, C1_, EPT_)                                                                                   \
     {                                                                                                                      \
-        auto k = conv_pool_kernel<NT_, C1_>;                                                                               \
+        auto k = conv_pool_kernel<NT_, C1_, EPT_>;                                                                         \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                     \
         hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                                     \
     }
-    if (NT == 3 && cin1) UVAD_SINC_LAUNCH(3, true)
-    else if (NT == 3) UVAD_SINC_LAUNCH(3, false)
-    else if (cin1) UVAD_SINC_LAUNCH(2, true)
-    else UVAD_SINC_LAUNCH(2, false)
+    if (cin1) {
+        if (NT == 3) UVAD_SINC_LAUNCH(3, true, 8) else UVAD_SINC_LAUNCH(2, true, 8)
+    } else if (ept <= 32) {
+        if (NT == 3) UVAD_SINC_LAUNCH(3, false, 32) else UVAD_SINC_LAUNCH(2, false, 32)
+    } else {
+        if (NT == 3) UVAD_SINC_LAUNCH(3, false, 48) else UVAD_SINC_LAUNCH(2, false, 48)
+    }
 #undef UVAD_SINC_LAUNCH
     return hipGetLastError();
 }

@@ -34,7 +34,7 @@ struct StreamState { float *h = nullptr, *c = nullptr; size_t layer_stride = 0; 
 
 struct uvad_ctx {
     std::map<void *, StreamCounters> streams;   // host mirror of the lock-step stream groups, keyed by d_state
-    int device = 0;
+    int device = 0, n_cu = 256;
     bool has_fb = false, has_model = false, finalized = false, tables_set = false;
     uvad_fbank_cfg fb{};
     uvad_model_cfg mc{};
@@ -216,6 +216,7 @@ int uvad_create(int device, const uvad_fbank_cfg *fb, const uvad_model_cfg *mode
     HIPCHK(c, hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPCHK(c, hipGetDeviceProperties(&prop, device));
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(c, UVAD_E_HIP, std::string("libuvad is built for gfx950 only; device is ") + prop.gcnArchName);
     if (fb) {
@@ -391,11 +392,13 @@ int uvad_finalize(uvad_ctx *c) {
             const bool wshape = i == 0 ? (expect_shape(*w, {cout[0], kw[0]}) || expect_shape(*w, {cout[0], 1, kw[0]})) : expect_shape(*w, {cout[i], cin[i], kw[i]});
             if (!wshape || (b && !expect_shape(*b, {cout[i]})) || !expect_shape(*g, {cout[i]}) || !expect_shape(*be, {cout[i]}))
                 return fail(c, UVAD_E_ARG, "sincnet stage " + id + " tensor shape mismatch");
-            // W[n][k = ci*Kw + kw] -> [Kp/2][NW][2], zero padded in n and k (sincnet.hip B-operand layout)
-            const int Ktot = cin[i] * kw[i], Kp = (Ktot + 3) / 4 * 4, NW = (cout[i] + 31) / 32 * 32;
+            // W[n][ci][tap] -> W^T [k = tap*Cin + ci][NW], zero padded in n and k (sincnet.hip B-operand layout)
+            const int Ktot = cin[i] * kw[i], Kp = (Ktot + 7) / 8 * 8, NW = (cout[i] + 31) / 32 * 32;
             std::vector<float> wt((size_t)Kp * NW, 0.0f), bias((size_t)NW, 0.0f);
             for (int n = 0; n < cout[i]; ++n) {
-                for (int k = 0; k < Ktot; ++k) wt[((size_t)(k >> 1) * NW + n) * 2 + (k & 1)] = w->data[(size_t)n * Ktot + k];
+                for (int ci = 0; ci < cin[i]; ++ci)
+                    for (int t = 0; t < kw[i]; ++t)   // kernel K order: tap-major, channel-minor
+                        wt[(size_t)(t * cin[i] + ci) * NW + n] = w->data[((size_t)n * cin[i] + ci) * kw[i] + t];
                 if (b) bias[n] = b->data[n];
             }
             if ((r = dev_upload(c, wt.data(), wt.size(), &c->sn_wt[i]))) return r;
@@ -415,6 +418,7 @@ int uvad_sincnet_configure(uvad_ctx *c, const uvad_sincnet_cfg *q) {
     if (q->stride < 1 || q->kernel_size < 3 || q->k2 < 3 || q->k3 < 3 || q->n_filters < 1 || q->c2 < 1 || q->c3 < 1)
         return fail(c, UVAD_E_ARG, "bad SincNet configuration");
     const int cout[3] = {q->n_filters, q->c2, q->c3};
+    if ((q->n_filters & 1) || (q->c2 & 1)) return fail(c, UVAD_E_UNSUPPORTED, "SincNet input channel counts of the conv stages must be even");
     for (int i = 0; i < 3; ++i)
         if (cout[i] <= 32 || cout[i] > 96) return fail(c, UVAD_E_UNSUPPORTED, "SincNet channel counts must be in 33..96 (two or three 32-wide MFMA column tiles)");
     if (q->c3 != c->mc.in_dim) return fail(c, UVAD_E_ARG, "SincNet output channels != classifier encoding_dim");
@@ -422,9 +426,11 @@ int uvad_sincnet_configure(uvad_ctx *c, const uvad_sincnet_cfg *q) {
     const int cin[3] = {1, q->n_filters, q->c2}, kw[3] = {q->kernel_size, q->k2, q->k3};
     for (int i = 0; i < 3; ++i) {
         SincConvArgs a{};
-        a.Cin = cin[i]; a.Kw = kw[i]; a.stride = i == 0 ? q->stride : 1; a.Ktot = cin[i] * kw[i]; a.Kp = (a.Ktot + 3) / 4 * 4;
+        a.Cin = cin[i]; a.Kw = kw[i]; a.stride = i == 0 ? q->stride : 1; a.Ktot = cin[i] * kw[i]; a.Kp = (a.Ktot + 7) / 8 * 8;
         if (sinc_conv_lds_bytes(a, (cout[i] + 31) / 32) > (size_t)160 * 1024)
             return fail(c, UVAD_E_UNSUPPORTED, "SincNet stage does not fit the 160 KiB LDS (filter matrix is LDS-resident)");
+        if (sinc_conv_ept(a) > (i == 0 ? 8 : 48))
+            return fail(c, UVAD_E_UNSUPPORTED, "SincNet stage input window too large for the register-prefetched staging");
     }
     c->sc = *q;
     c->has_sinc = true;
@@ -447,7 +453,6 @@ size_t uvad_sincnet_workspace_bytes(const uvad_ctx *c, int B, int64_t S) {
 static int sincnet_impl(uvad_ctx *c, const float *d_wav, int B, int64_t S, float *d_feats, void *ws, size_t ws_bytes, hipStream_t s) {
     if (!c->has_sinc) return fail(c, UVAD_E_STATE, "uvad_sincnet: uvad_sincnet_configure has not been called");
     if (!c->finalized || !c->sinc_ready) return fail(c, UVAD_E_STATE, "uvad_sincnet: SincNet tensors not set / uvad_finalize not called");
-    if (B > 65535) return fail(c, UVAD_E_UNSUPPORTED, "uvad_sincnet: B > 65535 (grid.y); split the batch");
     const SincLayout l = sinc_carve(c, B, S);
     if (!l.ok) return fail(c, UVAD_E_ARG, "uvad_sincnet: waveform too short for one output frame");
     if (l.Lconv[0] > 0x7fffffff / 4) return fail(c, UVAD_E_UNSUPPORTED, "uvad_sincnet: waveform too long");
@@ -465,9 +470,9 @@ static int sincnet_impl(uvad_ctx *c, const float *d_wav, int B, int64_t S, float
         a.in = in; a.in_bstride = (long long)l.Cin[i] * l.Lin[i]; a.Cin = l.Cin[i]; a.Lin = (int)l.Lin[i];
         a.in_scale = in_scale; a.in_shift = in_shift; a.in_lrelu = i > 0; a.slope = q.leaky_slope;
         a.Wt2 = c->sn_wt[i]; a.bias = c->sn_bias[i];
-        a.Kw = l.Kw[i]; a.stride = l.stride[i]; a.Ktot = l.Cin[i] * l.Kw[i]; a.Kp = (a.Ktot + 3) / 4 * 4; a.Cout = l.Cout[i]; a.do_abs = i == 0;
+        a.Kw = l.Kw[i]; a.stride = l.stride[i]; a.Ktot = l.Cin[i] * l.Kw[i]; a.Kp = (a.Ktot + 7) / 8 * 8; a.Cout = l.Cout[i]; a.do_abs = i == 0;
         a.Lconv = (int)l.Lconv[i]; a.Lpool = (int)l.Lpool[i]; a.ntiles = l.ntiles[i];
-        a.out = P; a.partials = part; a.B = B;
+        a.out = P; a.partials = part; a.B = B; a.n_cu = c->n_cu;
         HIPCHK(c, launch_sinc_conv(a, s));
         HIPCHK(c, launch_norm_finalize(part, B, l.ntiles[i], l.NW[i], l.Cout[i], (int)l.Lpool[i], c->sn_g[i], c->sn_b[i], q.eps, sc,
                                        sc + (size_t)B * l.Cout[i], s));
