@@ -144,6 +144,14 @@ int uvad_stream_step(uvad_ctx *, const float *d_pcm_chunk, int B, int chunk, voi
 int uvad_median_filter(uvad_ctx *, const float *d_probs, int B, int T, int kernel, uint8_t *d_labels,
                        void *stream);
 
+/* Replaces: the per-frame run-length walk of get_new_cuts (src/scripts/predict.py:472-490) on 0/1 frame rows
+ * (the output of uvad_median_filter): run i of row b is d_runs[b][i] = {first speech frame, first non-speech frame
+ * after it (T if the run is open at the end)}, in order; d_counts[b] = number of runs in the row (runs beyond
+ * max_runs are counted but not stored; a row of T frames has at most (T+1)/2).  The host turns frames into seconds
+ * with the reference's rounding (round(k*shift, 2), drop empty intervals). */
+int uvad_label_runs(uvad_ctx *, const uint8_t *d_labels, int B, int T, int max_runs, int32_t *d_runs /*[B][max_runs][2]*/,
+                    int32_t *d_counts /*[B]*/, void *stream);
+
 /* Replaces: get_false_alarm / get_missed_detection (src/scripts/predict.py:666-673) on 0/1 frame rows:
  * d_counts [B][2] uint32 = {#(gt == 0 and pred == 1), #(gt == 1 and pred == 0)} per row; the reference's
  * FA / MD / DER are these counts divided by the row length (DER = FA + MD, vad_engine.py:102-105). */

@@ -305,6 +305,38 @@ def test_both_gemm_modes_meet_the_logit_bound(mode):
     assert err < LOGIT_TOL
 
 
+def test_label_runs_on_device_equal_the_host_walk_and_the_oracle():
+    """uvad_label_runs + labels_to_intervals_batch == labels_to_intervals (numpy restatement of predict.py:472-490)
+    == the C oracle's orc_intervals, on random rows and the edge cases (empty, all speech, run open at the end,
+    single-frame runs, alternating frames = the (T+1)/2 maximum, T not a multiple of 64, T = 1)."""
+    import uvad_amd
+    from oracle import c_oracle
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    for T in (1, 7, 64, 65, 1000, 3001):
+        rows = [np.zeros(T, np.uint8), np.ones(T, np.uint8), (np.arange(T) % 2).astype(np.uint8), ((np.arange(T) + 1) % 2).astype(np.uint8)]
+        for p in (0.02, 0.3, 0.9):
+            r = (rng.random(T) < 0.5).astype(np.uint8)
+            for _ in range(3):   # smooth into runs of assorted lengths
+                r = (np.convolve(r, np.ones(5), "same") > 5 * p).astype(np.uint8)
+            rows.append(r)
+        tail = np.zeros(T, np.uint8); tail[T // 2:] = 1
+        rows.append(tail)
+        lab = np.stack(rows)
+        got = uvad_amd.labels_to_intervals_batch(torch.from_numpy(lab).to(dev), 0.01)
+        runs, counts = uvad_amd.postprocess._shared_runtime(dev).label_runs(torch.from_numpy(lab).to(dev))
+        for b in range(lab.shape[0]):
+            assert got[b] == uvad_amd.labels_to_intervals(lab[b], 0.01), (T, b)
+            assert got[b] == [tuple(x) for x in c_oracle.intervals(lab[b], 0.01)], (T, b)
+            d = np.diff(np.concatenate(([0], lab[b].astype(np.int8), [0])))
+            assert int(counts[b]) == int((d == 1).sum())
+    # overflow is reported, not silently truncated: counts holds the true number of runs
+    alt = torch.from_numpy((np.arange(200) % 2).astype(np.uint8)[None]).to(dev)
+    runs, counts = uvad_amd.postprocess._shared_runtime(dev).label_runs(alt, max_runs=8)
+    assert int(counts[0]) == 100 and runs.shape == (1, 8, 2)
+    assert runs[0, :, 0].cpu().tolist() == [1, 3, 5, 7, 9, 11, 13, 15]
+
+
 def test_detection_error_counts_match_numpy():
     """predict.py:666-673 on the GPU: FA = #(gt==0 & pred==1)/N, MD = #(gt==1 & pred==0)/N, DER = FA + MD."""
     import uvad_amd

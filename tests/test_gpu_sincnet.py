@@ -131,3 +131,30 @@ def test_vadmodel_pyannet_predict_step():
     # labels may differ only where a probability sits within tolerance of the 0.5 threshold
     near = np.abs(want_probs.numpy() - 0.5) < 1e-3
     assert (got != want).sum() <= near.sum()
+
+
+@pytest.mark.parametrize("name", ["pyannet_sincnet_S24000", "pyannet_sincnet_S80000"])
+def test_pyannet_matches_reference_class_golden(name):
+    """uvad_amd.PyanNet loaded with the reference model's own state_dict vs the outputs of the reference's SincNet /
+    PyanNet classes (tests/golden/pyannet_sincnet_*.npz, tools/gen_golden_sincnet.py)."""
+    import os
+    import uvad_amd
+    from oracle import torch_ref as tr
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"), allow_pickle=False)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd:")}
+    sd.update(tr.seeded_state_dict(60, seed=1234, scale=4.0))
+    m = uvad_amd.PyanNet()
+    m.build()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("filterbank" in k for k in missing), (missing, unexpected)
+    m = m.to("cuda:0").eval()
+    assert np.array_equal(m.sincnet.conv1d[0].filterbank.filters()[:, 0].numpy(), g["filters"])
+    wav = torch.from_numpy(g["wav"]).cuda()
+    feats = m.sincnet(wav.unsqueeze(1))                      # (B, 60, frames), the reference's layout
+    probs = m(wav.unsqueeze(1)).squeeze(-1)
+    torch.cuda.synchronize()
+    ferr = np.abs(feats.cpu().numpy() - g["sincnet_out"]).max()
+    perr = np.abs(probs.cpu().numpy() - g["probs"]).max()
+    print(f"{name}: SincNet feature err {ferr:.2e}, probability err {perr:.2e} vs the reference classes")
+    assert feats.shape == g["sincnet_out"].shape and ferr < FEAT_TOL
+    assert perr < LOGIT_TOL

@@ -116,3 +116,46 @@ def test_median_filter_and_intervals_vs_scipy():
     lab = np.array([0, 1, 1, 1, 0, 0, 1, 0, 1, 1], np.uint8)
     # predict.py:472-490: (k*shift, (k2-1)*shift), dropped when end-start <= 0, open run closed at len-1
     assert co.intervals(lab, 0.01) == [(0.01, 0.03), (0.08, 0.09)]
+
+
+# ---- SincNet front end -------------------------------------------------------------------------------
+
+SINC_GOLDENS = ("pyannet_sincnet_S24000", "pyannet_sincnet_S80000")
+
+
+def _load_sinc_golden(name):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"), allow_pickle=False)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd:")}
+    return g, sd
+
+
+@pytest.mark.parametrize("name", SINC_GOLDENS)
+def test_sincnet_restatement_matches_reference_class_golden(name):
+    """oracle.torch_ref.TorchSincNet + TorchPyanNet2(60) reproduce what the reference's own SincNet / PyanNet classes
+    produced (tools/gen_golden_sincnet.py): pins the order of norm / pool / activation / rearrange and the frame count.
+    The filter bank is the restated ParamSincFB on both sides (asteroid is absent: PARITY UNPINNED for that layer)."""
+    import hashlib
+    from oracle import torch_ref as tr
+    g, sd = _load_sinc_golden(name)
+    front = tr.TorchSincNet().eval()
+    fsd = {"wav_norm1d.weight": sd["sincnet.wav_norm1d.weight"], "wav_norm1d.bias": sd["sincnet.wav_norm1d.bias"],
+           "low_hz_": sd["sincnet.conv1d.0.filterbank.low_hz_"], "band_hz_": sd["sincnet.conv1d.0.filterbank.band_hz_"]}
+    for i in range(3):
+        for p in ("weight", "bias"):
+            fsd[f"norm1d.{i}.{p}"] = sd[f"sincnet.norm1d.{i}.{p}"]
+    for i in range(2):
+        for p in ("weight", "bias"):
+            fsd[f"conv1d.{i}.{p}"] = sd[f"sincnet.conv1d.{i + 1}.{p}"]
+    front.load_state_dict(fsd)
+    assert torch.equal(tr.sinc_filters(front.low_hz_, front.band_hz_), torch.from_numpy(g["filters"]))
+    wav = torch.from_numpy(g["wav"])
+    feats = front(wav.unsqueeze(1))
+    assert feats.shape == g["sincnet_out"].shape and feats.shape[2] == tr.sincnet_num_frames(wav.shape[1])
+    assert np.abs(feats.numpy() - g["sincnet_out"]).max() < 1e-5
+    csd = tr.seeded_state_dict(60, seed=1234, scale=4.0)
+    assert hashlib.sha256(b"".join(csd[k].numpy().tobytes() for k in sorted(csd))).hexdigest() == str(g["classifier_sha256"])
+    cls = tr.TorchPyanNet2(60)
+    cls.load_state_dict(csd)
+    _, probs = cls(feats.transpose(1, 2).contiguous())
+    assert np.abs(probs.numpy() - g["probs"]).max() < 1e-5

@@ -5,12 +5,12 @@ from .config import ConfigDict, load_config
 from .engine import VadModel
 from .features import Fbank, FbankConfig, make_mel_matrix, make_window
 from .models import PyanNet, PyanNet2
-from .postprocess import (detection_error, intervals_to_labels, labels_to_intervals, median_filter, median_window,
+from .postprocess import (detection_error, intervals_to_labels, labels_to_intervals, labels_to_intervals_batch, median_filter, median_window,
                           merge_intervals_with_buffer, split_into_windows)
 from .runtime import VadRuntime
 from .scripts import predict_vad
 from .sincnet import SincNet
 
 __all__ = ["ConfigDict", "load_config", "VadModel", "Fbank", "FbankConfig", "make_mel_matrix", "make_window",
-           "PyanNet", "PyanNet2", "SincNet", "VadRuntime", "labels_to_intervals", "median_filter", "median_window", "predict_vad",
+           "PyanNet", "PyanNet2", "SincNet", "VadRuntime", "labels_to_intervals", "labels_to_intervals_batch", "median_filter", "median_window", "predict_vad",
            "detection_error", "intervals_to_labels", "merge_intervals_with_buffer", "split_into_windows"]

@@ -64,6 +64,7 @@ SIGNATURES = {
     "uvad_stream_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "uvad_median_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "uvad_label_runs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uvad_der_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "uvad_set_gemm_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "uvad_set_timing": (C.c_int, [C.c_void_p, C.c_int]),

@@ -5,6 +5,7 @@
 //   untile     : tile-major activation rows -> canonical [B][T][W] (parity taps)
 //   median     : threshold 0.5 + odd binary median, zero padded edges
 //                (reference: median_filter, src/utils/helper.py:66-97, i.e. scipy.signal.medfilt)
+//   runs       : 0/1 label rows -> (start, stop) frame pairs (reference: get_new_cuts, predict.py:472-490)
 // All three are HBM-bound streaming kernels: 16-byte loads, wave-shuffle reductions, no LDS.
 #include "uvad_internal.h"
 
@@ -116,7 +117,44 @@ __global__ __launch_bounds__(256) void der_kernel(const uint8_t *pred, const uin
     if (lane == 0) { counts[2 * b] = fa; counts[2 * b + 1] = md; }
 }
 
+// Run-length extraction of 0/1 label rows (reference: the per-frame Python walk of get_new_cuts,
+// src/scripts/predict.py:472-490): run i of row b starts at frame runs[b][i][0] (label 0 -> 1) and its first
+// non-speech frame is runs[b][i][1] (T when the run is still open at the end).  One wave per row walks the row 64
+// frames at a time; a ballot + popcount of the lanes below gives each edge its rank, so runs come out in order.
+// counts[b] is the true number of runs even when it exceeds max_runs (the host checks for overflow).
+__global__ __launch_bounds__(256) void runs_kernel(const uint8_t *labels, int B, int T, int max_runs, int *runs, int *counts) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const uint8_t *p = labels + (size_t)b * T;
+    int *r = runs + (size_t)b * max_runs * 2;
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int n_start = 0, n_stop = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const bool in = t < T;
+        const unsigned cur = in ? (p[t] & 1u) : 0u;
+        const unsigned prev = (in && t > 0) ? (p[t - 1] & 1u) : 0u;
+        const bool is_start = in && cur && !prev, is_stop = in && !cur && prev;
+        const unsigned long long ms = __ballot(is_start), me = __ballot(is_stop);
+        if (is_start) { const int i = n_start + __popcll(ms & below); if (i < max_runs) r[2 * i] = t; }
+        if (is_stop) { const int i = n_stop + __popcll(me & below); if (i < max_runs) r[2 * i + 1] = t; }
+        n_start += __popcll(ms);
+        n_stop += __popcll(me);
+    }
+    if (lane == 0) {
+        if (n_start > n_stop && n_stop < max_runs) r[2 * n_stop + 1] = T;   // run still open at the end of the row
+        counts[b] = n_start;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_runs(const uint8_t *labels, int B, int T, int max_runs, int *runs, int *counts, hipStream_t s) {
+    if (B <= 0 || T <= 0) return hipSuccess;
+    hipLaunchKernelGGL(runs_kernel, dim3((B + 3) / 4), dim3(256), 0, s, labels, B, T, max_runs, runs, counts);
+    return hipGetLastError();
+}
 
 hipError_t launch_der(const uint8_t *pred, const uint8_t *gt, int B, int T, uint32_t *counts, hipStream_t s) {
     if (B <= 0 || T <= 0) return hipSuccess;

@@ -828,6 +828,12 @@ int uvad_der_counts(uvad_ctx *c, const uint8_t *d_pred, const uint8_t *d_gt, int
     return UVAD_OK;
 }
 
+int uvad_label_runs(uvad_ctx *c, const uint8_t *d_labels, int B, int T, int max_runs, int32_t *d_runs, int32_t *d_counts, void *stream) {
+    if (!c || !d_labels || !d_runs || !d_counts || B <= 0 || T <= 0 || max_runs <= 0) return UVAD_E_ARG;
+    HIPCHK(c, launch_runs(d_labels, B, T, max_runs, d_runs, d_counts, (hipStream_t)stream));
+    return UVAD_OK;
+}
+
 int uvad_set_gemm_mode(uvad_ctx *c, int mode) {
     if (!c) return UVAD_E_ARG;
     if (mode != 0 && mode != 1) return fail(c, UVAD_E_ARG, "gemm mode must be 0 (exact f32 MFMA) or 1 (split-bf16 x6)");

@@ -79,6 +79,8 @@ hipError_t launch_classifier(const ClsArgs &a, hipStream_t s);
 hipError_t launch_untile(const float *src, int lds_, int W, float *dst, int tiles, int T, int B, hipStream_t s);
 // threshold 0.5 + binary median
 hipError_t launch_median(const float *probs, int B, int T, int kernel, uint8_t *labels, hipStream_t s);
+// 0/1 label rows -> ordered (start frame, first non-speech frame) pairs per row + the number of runs
+hipError_t launch_runs(const uint8_t *labels, int B, int T, int max_runs, int *runs, int *counts, hipStream_t s);
 // per-row {false alarm, missed detection} frame counts of 0/1 label rows
 hipError_t launch_der(const uint8_t *pred, const uint8_t *gt, int B, int T, uint32_t *counts, hipStream_t s);
 

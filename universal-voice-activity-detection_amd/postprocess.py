@@ -56,6 +56,31 @@ def labels_to_intervals(labels, frame_shift: float) -> List[Tuple[float, float]]
     return out
 
 
+def labels_to_intervals_batch(labels: torch.Tensor, frame_shift: float, runtime=None) -> List[List[Tuple[float, float]]]:
+    """(B, T) 0/1 labels ON THE GPU -> per row [(start_s, end_s)], same values as ``labels_to_intervals`` row by row.
+    The run-length walk runs in ``uvad_label_runs``; only the (start, stop) frame pairs cross to the host (one copy
+    for the whole batch), where the reference's rounding / empty-interval rule is applied."""
+    if not (torch.is_tensor(labels) and labels.is_cuda):
+        raise RuntimeError("labels_to_intervals_batch runs on the GPU only (use labels_to_intervals for host rows)")
+    if labels.dim() == 3:
+        labels = labels.squeeze(-1)
+    rt = runtime or _shared_runtime(labels.device)
+    T = labels.shape[1]
+    runs, counts = rt.label_runs(labels)
+    counts_h = counts.cpu().numpy()
+    runs_h = runs[:, : max(int(counts_h.max()), 1)].cpu().numpy()
+    out = []
+    for b in range(labels.shape[0]):
+        row = []
+        for k, k2 in runs_h[b, : counts_h[b]]:
+            last = (T - 1) if k2 >= T else (k2 - 1)
+            s, e = round(float(k * frame_shift), 2), round(float(last * frame_shift), 2)
+            if e - s > 0.0:
+                row.append((s, e))
+        out.append(row)
+    return out
+
+
 # ---- scoring side of get_new_cuts (src/scripts/predict.py:500-509, 612-673) -----------------------------------
 
 def merge_intervals_with_buffer(intervals, total_duration: float, buffer: float):

@@ -270,6 +270,19 @@ class VadRuntime:
             self._check(self.lib.uvad_der_counts(self.ctx, pred.data_ptr(), gt.data_ptr(), B, T, out.data_ptr(), self._stream()))
             return out
 
+    def label_runs(self, labels: "torch.Tensor", max_runs: int = 0):
+        """labels (B, T) uint8 0/1 on the GPU -> (runs (B, max_runs, 2) int32, counts (B,) int32), both on the GPU."""
+        with torch.cuda.device(self.device):
+            if not torch.is_tensor(labels) or labels.device != self.device:
+                raise RuntimeError(f"labels must be a tensor on {self.device}")
+            labels = labels.to(torch.uint8).contiguous()
+            B, T = labels.shape
+            max_runs = int(max_runs) if max_runs > 0 else (T + 1) // 2
+            runs = torch.empty((B, max_runs, 2), dtype=torch.int32, device=self.device)
+            counts = torch.empty((B,), dtype=torch.int32, device=self.device)
+            self._check(self.lib.uvad_label_runs(self.ctx, labels.data_ptr(), B, T, max_runs, runs.data_ptr(), counts.data_ptr(), self._stream()))
+            return runs, counts
+
     def set_timing(self, on: bool):
         self._check(self.lib.uvad_set_timing(self.ctx, int(on)))
 

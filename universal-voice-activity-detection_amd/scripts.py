@@ -14,7 +14,7 @@ import torch
 
 from .engine import VadModel
 from .features import Fbank, FbankConfig
-from .postprocess import labels_to_intervals
+from .postprocess import labels_to_intervals_batch
 from .synth import seed_weights, synth_pcm
 
 
@@ -88,11 +88,12 @@ def predict_vad(**kwargs):
         batch = {"inputs": feats, "input_lens": torch.full((len(group),), feats.shape[1]), "cut": [recs[j]["id"] for j in group]}
         labels = model.predict_step(batch, 0).squeeze(-1)          # (B, T) 0/1
         probs = model(feats).squeeze(-1)
+        intervals = labels_to_intervals_batch(labels, frame_shift)   # run-length walk on the GPU (uvad_label_runs)
         labels_h, probs_h = labels.cpu().numpy(), probs.cpu().numpy()
         for r, j in enumerate(group):
             results.append({"recording_id": recs[j]["id"], "num_frames": int(labels_h.shape[1]),
                             "labels": labels_h[r].astype(np.uint8), "probs": probs_h[r],
-                            "intervals": labels_to_intervals(labels_h[r], frame_shift)})
+                            "intervals": intervals[r]})
     results.sort(key=lambda r: r["recording_id"])
 
     out_dir = kwargs.get("predict_output_dir") or ""
