@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU (default = BASELINE cfg 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-batches-in-flight measurement")
+    ap.add_argument("--no-sincnet", action="store_true", help="skip the extra PyanNet (SincNet front end) measurement")
     args = ap.parse_args()
 
     import uvad_amd
@@ -150,6 +151,8 @@ def main():
 
     if not args.no_pipelined:
         out["pipelined"] = pipelined_throughput(model, dev, pcm, args.steps, world)
+    if rank == 0 and world == 1 and not args.no_sincnet:
+        out["pyannet_sincnet"] = sincnet_throughput(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out.update(cpu_baseline_and_error(model, rt, pcm, dev))
     if rank == 0:
@@ -189,6 +192,42 @@ def pipelined_throughput(model, dev, pcm, steps, world):
         r.close()
     return {"value": frames / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "batches_in_flight": 2,
             "note": "same K steps, two independent batches in flight on two HIP streams; not the headline value"}
+
+
+def sincnet_throughput(dev, B=256, S=80000, reps=5):
+    """Extra, NOT the headline value: the PyanNet waveform model on the reference's 5 s cuts (80000
+    samples -> 293 frames, src/datasets/custom_vad.py:47).  SincNet work per cut: 7975*80*251 + 2654*60*400 +
+    880*60*300 multiply-adds; bound = f32 MFMA (v_mfma_f32_32x32x2_f32 implicit GEMM)."""
+    import uvad_amd
+    from uvad_amd.synth import seed_weights, synth_pcm_device
+    m = uvad_amd.PyanNet()
+    m.build()
+    seed_weights(m, 1234, 4.0)   # classifier only; the SincNet front end keeps its mel-spaced initialisation
+    m = m.to(dev).eval()
+    rt = m.runtime(dev)
+    wav = synth_pcm_device(B, S, 1000, dev)
+    T = rt.sincnet_num_frames(S)
+
+    def timed(fn):
+        fn(); torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps
+
+    ms_front = timed(lambda: rt.sincnet(wav))
+    ms_all = timed(lambda: rt.forward_wav(wav, want_probs=False))
+    L1 = (S - 251) // 10 + 1; L2 = L1 // 3 - 4; L3 = L2 // 3 - 4
+    flop = 2.0 * (L1 * 80 * 251 + L2 * 60 * 400 + L3 * 60 * 300) * B
+    tf = flop / (ms_front * 1e-3) / 1e12
+    rt.close()
+    return {"workload": f"batch={B} x 5 s waveforms -> {T} frames each (PyanNet: SincNet + 4xBiLSTM(128) + 2xFC)",
+            "frames_per_s": B * T / (ms_all * 1e-3), "audio_seconds_per_s": B * S / 16000.0 / (ms_all * 1e-3), "ms_per_step": ms_all,
+            "sincnet_ms": ms_front, "sincnet_roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                         "frac": tf / PEAK_F32_MFMA_TFLOPS, "flops_per_step": flop},
+            "note": "alternative waveform front end; not the headline value"}
 
 
 def cpu_baseline_and_error(model, rt, pcm, dev):

@@ -9,7 +9,11 @@ int main() {
     int L = 80000;
     for (int i = 0; i < 3; ++i) {
         const int Lconv = (L - kw[i]) / stride[i] + 1, Lpool = Lconv / 3, NW = (cout[i] + 31) / 32 * 32;
-        const int Ktot = cin[i] * kw[i], Kp = (Ktot + 7) / 8 * 8, ntiles = (Lpool + 31) / 32;
+        const int Ktot = cin[i] * kw[i], Kp = (Ktot + 7) / 8 * 8;
+        uvad::SincConvArgs pa{};
+        pa.Cin = cin[i]; pa.Cout = cout[i]; pa.Kw = kw[i]; pa.stride = stride[i]; pa.Ktot = Ktot; pa.Kp = Kp;
+        const uvad::SincConvPlan plan = uvad::sinc_conv_plan(pa);
+        const int ntiles = (Lpool + plan.pt - 1) / plan.pt;
         float *in, *sc, *sh, *wt, *bias, *out, *part;
         hipMalloc(&in, (size_t)B * cin[i] * L * 4); hipMemset(in, 0, (size_t)B * cin[i] * L * 4);
         hipMalloc(&sc, (size_t)B * cin[i] * 4); hipMemset(sc, 0, (size_t)B * cin[i] * 4);
@@ -17,7 +21,7 @@ int main() {
         hipMalloc(&wt, (size_t)Kp * NW * 4); hipMemset(wt, 0, (size_t)Kp * NW * 4);
         hipMalloc(&bias, NW * 4); hipMemset(bias, 0, NW * 4);
         hipMalloc(&out, (size_t)B * cout[i] * Lpool * 4);
-        hipMalloc(&part, (size_t)B * ntiles * NW * 2 * 4);
+        hipMalloc(&part, (size_t)B * ntiles * plan.phases * NW * 2 * 4);
         uvad::SincConvArgs a{};
         a.in = in; a.in_bstride = (long long)cin[i] * L; a.Cin = cin[i]; a.Lin = L; a.in_scale = sc; a.in_shift = sh; a.in_lrelu = i > 0; a.slope = 0.01f;
         a.Wt2 = wt; a.bias = bias; a.Kw = kw[i]; a.stride = stride[i]; a.Ktot = Ktot; a.Kp = Kp; a.Cout = cout[i]; a.do_abs = i == 0;
@@ -32,8 +36,8 @@ int main() {
         ms /= 5;
         const double flop = 2.0 * B * (double)Lconv * cout[i] * Ktot;
         const double tiles_per_cu = (double)B * ntiles / 256.0;
-        printf("%s stage %d: %.3f ms = %.1f TFLOP/s (%.2f us per tile-slot; MFMA-only bound %.2f us at 2.4 GHz)\n", ABL_NAME, i, ms, flop / ms / 1e9,
-               ms * 1e3 / tiles_per_cu, (Kp / 2) * ((cout[i] + 31) / 32) * 64 / 2400.0);
+        printf("%s stage %d (%d waves): %.3f ms = %.1f TFLOP/s (%.2f us per tile-slot; MFMA-only bound %.2f us at 2.4 GHz)\n", ABL_NAME, i, plan.waves, ms,
+               flop / ms / 1e9, ms * 1e3 / tiles_per_cu, (Kp / 2) * ((cout[i] + 31) / 32) * 64 / 2400.0 * (plan.waves == 8 ? 2 : 1));
         hipFree(in); hipFree(sc); hipFree(sh); hipFree(wt); hipFree(bias); hipFree(out); hipFree(part);
         L = Lpool;
     }

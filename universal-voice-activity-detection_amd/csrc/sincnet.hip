@@ -41,27 +41,36 @@ __device__ __forceinline__ float half_sum(float v, bool upper) {
     return upper ? hi : lo;
 }
 
-constexpr int CT = 96;        // conv positions per tile (3 waves x 32 MFMA rows) = 32 pooled outputs
 constexpr int YS = 97;        // LDS row stride of the conv-output staging tile
 
-__global__ __launch_bounds__(256) void wav_stats_kernel(const float *wav, long long S, long long row_stride, const float *gamma,
-                                                        const float *beta, float eps, float *scale, float *shift) {
+__global__ __launch_bounds__(1024) void wav_stats_kernel(const float *wav, long long S, long long row_stride, const float *gamma,
+                                                         const float *beta, float eps, float *scale, float *shift) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const float *x = wav + (size_t)b * row_stride;
     double s = 0.0, ss = 0.0;
-    for (long long i = tid; i < S; i += 256) {
+    long long i0 = 0;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {   // 16-byte loads, 1024 threads: the whole row is in flight at once
+        const long long n4 = S >> 2;
+        for (long long i = tid; i < n4; i += 1024) {
+            const float4 v = reinterpret_cast<const float4 *>(x)[i];
+            s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+            ss += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+        }
+        i0 = n4 << 2;
+    }
+    for (long long i = i0 + tid; i < S; i += 1024) {
         const double v = x[i];
         s += v;
         ss += v * v;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
-    __shared__ double red[2][4];
+    __shared__ double red[2][16];
     if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = ss; }
     __syncthreads();
     if (tid == 0) {
-        s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        ss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        s = 0.0; ss = 0.0;
+        for (int w = 0; w < 16; ++w) { s += red[0][w]; ss += red[1][w]; }
         const double mean = s / (double)S;
         double var = ss / (double)S - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -71,9 +80,14 @@ __global__ __launch_bounds__(256) void wav_stats_kernel(const float *wav, long l
     }
 }
 
-template <int NT, bool CIN1, int EPT>
-__global__ __launch_bounds__(192) void conv_pool_kernel(SincConvArgs a) {
+template <int NT, bool CIN1, int EPT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void conv_pool_kernel(SincConvArgs a) {
     constexpr int NW = NT * 32;
+    constexpr int NTHR = WAVES * 64;
+    constexpr int CTW = WAVES * 32;            // conv positions computed per tile (one 32-row MFMA block per wave)
+    constexpr int TA = CTW / 3 * 3;            // positions the tile advances by (pool windows never straddle tiles)
+    constexpr int PT = TA / 3;                 // pooled outputs per tile
+    constexpr int PHASES = (WAVES + 2) / 3;    // the epilogue runs in groups of three waves = 96 positions = 32 pooled
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // (scale, shift) of the current utterance's input norm: a separate LDS object, so the compiler knows the window
     // stores below cannot alias it (with one array every store waited for the previous (scale, shift) read)
@@ -82,7 +96,7 @@ __global__ __launch_bounds__(192) void conv_pool_kernel(SincConvArgs a) {
     float *xy = smem + (size_t)a.Kp * NW;              // input window [Cin][XW] (+ zero pad, + 1 dump slot) / conv-output tile [NW][YS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kk = lane >> 5;
-    const int XW = (CT - 1) * a.stride + a.Kw;
+    const int XW = (CTW - 1) * a.stride + a.Kw;
     const int nelem = a.Cin * XW;                      // real elements of the window
     const int npad = 8;                                // the Kp - Ktot <= 7 zero-weight padded k read taps >= Kw: <= 7 elements past the window
     const int dump = nelem + npad;                     // where the staging stores of threads past the window go
@@ -99,28 +113,28 @@ __global__ __launch_bounds__(192) void conv_pool_kernel(SincConvArgs a) {
         const float4 *src = reinterpret_cast<const float4 *>(a.Wt2);
         float4 *dst = reinterpret_cast<float4 *>(wt);
         const int n4 = a.Kp * NW / 4;
-        for (int i0 = 0; i0 < n4; i0 += 192 * 8) {
+        for (int i0 = 0; i0 < n4; i0 += NTHR * 8) {
             float4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const int i = i0 + j * 192 + tid; v[j] = src[i < n4 ? i : 0]; }
+            for (int j = 0; j < 8; ++j) { const int i = i0 + j * NTHR + tid; v[j] = src[i < n4 ? i : 0]; }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const int i = i0 + j * 192 + tid; if (i < n4) dst[i] = v[j]; }
+            for (int j = 0; j < 8; ++j) { const int i = i0 + j * NTHR + tid; if (i < n4) dst[i] = v[j]; }
         }
     }
 
-    // Window element e of this thread is linear index idx = tid + 192*e of [Cin][XW] -> (ci, x), walked incrementally.
+    // Window element e of this thread is linear index idx = tid + NTHR*e of [Cin][XW] -> (ci, x), walked incrementally.
     const int ci0 = tid / XW, xs0 = tid - ci0 * XW;
-    const int qstep = 192 / XW, rstep = 192 - qstep * XW;
+    const int qstep = NTHR / XW, rstep = NTHR - qstep * XW;
     float pre[EPT];
 #define UVAD_SN_PREFETCH(g_)                                                               \
     {   /* 32-bit element offsets from the utterance's (wave-uniform) base: one address VGPR per load */ \
         const int b_ = (int)((g_) / a.ntiles), tile_ = (int)((g_) - (long long)b_ * a.ntiles); \
         const float *inb_ = a.in + (size_t)b_ * a.in_bstride;                              \
-        const int x0_ = tile_ * CT * a.stride;                                             \
+        const int x0_ = tile_ * TA * a.stride;                                             \
         int x_ = xs0;                                                                      \
         unsigned off_ = (unsigned)ci0 * (unsigned)a.Lin + (unsigned)(x0_ + xs0);           \
         _Pragma("unroll") for (int e = 0; e < EPT; ++e) {                                  \
-            const bool ok_ = tid + 192 * e < nelem && x0_ + x_ < a.Lin;                    \
+            const bool ok_ = tid + NTHR * e < nelem && x0_ + x_ < a.Lin;                   \
             pre[e] = inb_[ok_ ? off_ : 0u];                                                \
             x_ += rstep; off_ += (unsigned)qstep * (unsigned)a.Lin + (unsigned)rstep;      \
             if (x_ >= XW) { x_ -= XW; off_ += (unsigned)(a.Lin - XW); }                    \
@@ -146,7 +160,7 @@ __global__ __launch_bounds__(192) void conv_pool_kernel(SincConvArgs a) {
 #ifndef UVAD_SN_ABL_NOSTAGE
         {   // registers -> LDS with the previous stage's instance norm (+ leaky_relu) folded in; branch-free: threads
             // past the window store into a dump slot
-            const int x0 = tile * CT * a.stride;
+            const int x0 = tile * TA * a.stride;
             int ci = ci0, x = xs0;
 #pragma unroll
             for (int e0 = 0; e0 < EPT; e0 += 8) {   // eight (scale, shift) reads in flight, then eight stores
@@ -162,13 +176,13 @@ __global__ __launch_bounds__(192) void conv_pool_kernel(SincConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);   // keep the eight reads together (the scheduler pairs them otherwise)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int idx = tid + 192 * (e0 + j);
+                    const int idx = tid + NTHR * (e0 + j);
                     float v = __builtin_fmaf(pre[e0 + j], ns[j].x, ns[j].y);
                     if (a.in_lrelu) v = v >= 0.f ? v : v * a.slope;
                     xy[idx < nelem ? idx : dump] = in[j] ? v : 0.f;
                 }
             }
-            for (int i = tid; i < npad; i += 192) xy[nelem + i] = 0.f;   // what the zero-weight padded K steps read
+            for (int i = tid; i < npad; i += NTHR) xy[nelem + i] = 0.f;   // what the zero-weight padded K steps read
         }
 #endif
         __syncthreads();
@@ -249,42 +263,50 @@ __global__ __launch_bounds__(192) void conv_pool_kernel(SincConvArgs a) {
             continue;
         }
 #endif
+        // Epilogue in groups of three waves (96 positions = 32 pooled outputs, the size of the LDS output tile): bias,
+        // |.|, accumulators -> LDS; 3:1 max pool; coalesced store; and the group's (sum, M2 about its own mean) per
+        // channel -- combined in order by norm_finalize_kernel (Chan's update), which keeps the variance accurate when
+        // it is small against the mean.  Each 32-lane half owns one channel per pass (DPP half-wave sums).
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = t * 32 + li;
-            const float bias = a.bias[n];
+        for (int ph = 0; ph < PHASES; ++ph) {
+            if (PHASES > 1 && ph > 0) __syncthreads();   // the previous group's pooled reads are complete
+            if (wave / 3 == ph) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-                float v = acc[t][r] + bias;
-                if (a.do_abs) v = __builtin_fabsf(v);
-                xy[(size_t)n * YS + wave * 32 + row] = v;
+                for (int t = 0; t < NT; ++t) {
+                    const int n = t * 32 + li;
+                    const float bias = a.bias[n];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                        float v = acc[t][r] + bias;
+                        if (a.do_abs) v = __builtin_fabsf(v);
+                        xy[(size_t)n * YS + (wave % 3) * 32 + row] = v;
+                    }
+                }
             }
-        }
-        __syncthreads();
-
-        // 3:1 max pool, store, and the tile's (sum, M2 about the tile mean) per channel -- combined in tile order by
-        // norm_finalize_kernel (Chan's update), which keeps the variance accurate when it is small against the mean.
-        // Each 32-lane half owns one channel per pass; unrolled x4 so the passes' LDS reads and DPP chains overlap.
-        const int p0 = tile * (CT / 3);
-        const int nt = a.Lpool - p0 < 32 ? a.Lpool - p0 : 32;
-        const float inv_nt = 1.0f / (float)nt;
-        constexpr int PASSES = (NW + 5) / 6;
+            __syncthreads();
+            const int cap = ph == PHASES - 1 ? PT - 32 * (PHASES - 1) : 32;
+            const int p0 = tile * PT + 32 * ph;
+            int nt = a.Lpool - p0 < cap ? a.Lpool - p0 : cap;
+            if (nt < 0) nt = 0;
+            const float inv_nt = nt > 0 ? 1.0f / (float)nt : 0.f;
+            constexpr int PASSES = (NW + 2 * WAVES - 1) / (2 * WAVES);
 #pragma unroll 4
-        for (int j = 0; j < PASSES; ++j) {
-            const int n = j * 6 + wave * 2 + kk, p = li;
-            const int nc = n < NW ? n : NW - 1;
-            const float *y = xy + (size_t)nc * YS + 3 * p;
-            const float m = __builtin_fmaxf(__builtin_fmaxf(y[0], y[1]), y[2]);
-            const bool valid = n < a.Cout && p < nt;
-            if (valid) a.out[((size_t)b * a.Cout + n) * a.Lpool + p0 + p] = m;
-            const float s = half_sum(valid ? m : 0.f, kk != 0);
-            const float d = valid ? m - s * inv_nt : 0.f;
-            const float m2 = half_sum(d * d, kk != 0);
-            if (p == 0 && n < NW) {
-                float *pp = a.partials + (((size_t)b * a.ntiles + tile) * NW + n) * 2;
-                pp[0] = s;
-                pp[1] = m2;
+            for (int j = 0; j < PASSES; ++j) {
+                const int n = j * 2 * WAVES + wave * 2 + kk, p = li;
+                const int nc = n < NW ? n : NW - 1;
+                const float *y = xy + (size_t)nc * YS + 3 * p;
+                const float m = __builtin_fmaxf(__builtin_fmaxf(y[0], y[1]), y[2]);
+                const bool valid = n < a.Cout && p < nt;
+                if (valid) a.out[((size_t)b * a.Cout + n) * a.Lpool + p0 + p] = m;
+                const float s = half_sum(valid ? m : 0.f, kk != 0);
+                const float d = valid ? m - s * inv_nt : 0.f;
+                const float m2 = half_sum(d * d, kk != 0);
+                if (p == 0 && n < NW) {
+                    float *pp = a.partials + (((size_t)b * a.ntiles + tile) * PHASES + ph) * (NW * 2) + n * 2;
+                    pp[0] = s;
+                    pp[1] = m2;
+                }
             }
         }
     }
@@ -292,19 +314,23 @@ __global__ __launch_bounds__(192) void conv_pool_kernel(SincConvArgs a) {
 
 // per-tile (sum, M2) partials, combined in tile order -> per (b, c) affine of the instance norm:
 //   y = (x - mean) / sqrt(var + eps) * gamma + beta = x * scale + shift      (biased variance, torch InstanceNorm1d)
-__global__ __launch_bounds__(128) void norm_finalize_kernel(const float *partials, int ntiles, int NW, int C, int L, const float *gamma,
-                                                            const float *beta, float eps, float *scale, float *shift) {
+__global__ __launch_bounds__(128) void norm_finalize_kernel(const float *partials, int ntiles, int pt, int phases, int NW, int C, int L,
+                                                            const float *gamma, const float *beta, float eps, float *scale, float *shift) {
     const int b = blockIdx.x, n = threadIdx.x;
     if (n >= C) return;
     double mean = 0.0, M2 = 0.0, cnt = 0.0;
-    for (int t = 0; t < ntiles; ++t) {
-        const float *pp = partials + (((size_t)b * ntiles + t) * NW + n) * 2;
-        const double nt = (double)(L - 32 * t < 32 ? L - 32 * t : 32);
-        const double mt = (double)pp[0] / nt, delta = mt - mean, tot = cnt + nt;
-        M2 += (double)pp[1] + delta * delta * cnt * nt / tot;
-        mean += delta * nt / tot;
-        cnt = tot;
-    }
+    for (int t = 0; t < ntiles; ++t)
+        for (int ph = 0; ph < phases; ++ph) {   // the statistics groups of conv_pool_kernel, in position order
+            const int start = t * pt + 32 * ph, cap = ph == phases - 1 ? pt - 32 * (phases - 1) : 32;
+            const int ni = L - start < cap ? L - start : cap;
+            if (ni <= 0) continue;
+            const float *pp = partials + (((size_t)b * ntiles + t) * phases + ph) * (NW * 2) + n * 2;
+            const double nt = (double)ni;
+            const double mt = (double)pp[0] / nt, delta = mt - mean, tot = cnt + nt;
+            M2 += (double)pp[1] + delta * delta * cnt * nt / tot;
+            mean += delta * nt / tot;
+            cnt = tot;
+        }
     const double var = M2 / (double)L;
     const double sc = (double)gamma[n] / sqrt(var + (double)eps);
     scale[(size_t)b * C + n] = (float)sc;
@@ -327,59 +353,79 @@ __global__ __launch_bounds__(256) void sinc_out_kernel(const float *P, const flo
 
 }  // namespace
 
-size_t sinc_conv_lds_bytes(const SincConvArgs &a, int NT) {
+static int sinc_window(const SincConvArgs &a, int waves) { return (waves * 32 - 1) * a.stride + a.Kw; }
+
+size_t sinc_conv_lds_bytes(const SincConvArgs &a, int NT, int waves) {
     const int NW = NT * 32;
-    const int XW = (CT - 1) * a.stride + a.Kw;
-    size_t xy = (size_t)a.Cin * XW + 8 + 1;
+    size_t xy = (size_t)a.Cin * sinc_window(a, waves) + 8 + 1;
     if (xy < (size_t)NW * YS) xy = (size_t)NW * YS;
     return ((size_t)a.Kp * NW + xy) * sizeof(float) + 96 * sizeof(float2);   // + the static (scale, shift) table
 }
 
-// elements of the input window each of the 192 threads carries in registers between tiles
-int sinc_conv_ept(const SincConvArgs &a) {
-    const int XW = (CT - 1) * a.stride + a.Kw;
-    return (a.Cin * XW + 191) / 192;
+// elements of the input window each thread carries in registers between tiles
+int sinc_conv_ept(const SincConvArgs &a, int waves) { return (a.Cin * sinc_window(a, waves) + waves * 64 - 1) / (waves * 64); }
+
+// Workgroup shape of a stage: 8 waves (two per SIMD, 255 positions = 85 pooled outputs per tile) when the filter
+// matrix + window fit the LDS and the window fits the register staging -- the single-channel sinc stage --
+// 4 waves for the multi-channel stages under the same conditions, else 3 waves (96 positions = 32 pooled outputs).
+SincConvPlan sinc_conv_plan(const SincConvArgs &a) {
+    const int NT = (a.Cout + 31) / 32;
+    SincConvPlan p;
+    const bool wide = a.Cin == 1 && sinc_conv_lds_bytes(a, NT, 8) <= (size_t)160 * 1024 && sinc_conv_ept(a, 8) <= 8;
+    // multi-channel stages: 4 waves (one per SIMD, 126 positions = 42 pooled outputs) when the wider window still fits
+    const bool four = a.Cin > 1 && sinc_conv_lds_bytes(a, NT, 4) <= (size_t)160 * 1024 && sinc_conv_ept(a, 4) <= 48;
+    p.waves = wide ? 8 : four ? 4 : 3;
+    p.pt = p.waves * 32 / 3;
+    p.phases = (p.waves + 2) / 3;
+    return p;
 }
 
 hipError_t launch_wav_stats(const float *wav, int B, long long S, long long row_stride, const float *gamma, const float *beta, float eps,
                             float *scale, float *shift, hipStream_t s) {
-    hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(256), 0, s, wav, S, row_stride, gamma, beta, eps, scale, shift);
+    hipLaunchKernelGGL(wav_stats_kernel, dim3(B), dim3(1024), 0, s, wav, S, row_stride, gamma, beta, eps, scale, shift);
     return hipGetLastError();
 }
 
 hipError_t launch_sinc_conv(const SincConvArgs &a, hipStream_t s) {
     const int NT = (a.Cout + 31) / 32;
     if (NT != 2 && NT != 3) return hipErrorInvalidValue;
-    const size_t lds = sinc_conv_lds_bytes(a, NT);
+    const SincConvPlan plan = sinc_conv_plan(a);
+    if (a.ntiles != (a.Lpool + plan.pt - 1) / plan.pt) return hipErrorInvalidValue;   // the caller sized the partials with the same plan
+    const size_t lds = sinc_conv_lds_bytes(a, NT, plan.waves);
     // persistent workgroups, one per CU (the LDS-resident filter matrix allows no more), each walking a contiguous
     // range of the (utterance, tile) pairs
     const long long total = (long long)a.B * a.ntiles;
     const int ncu = a.n_cu > 0 ? a.n_cu : 256;
-    const dim3 grid((unsigned)(total < ncu ? total : ncu)), block(192);
+    const dim3 grid((unsigned)(total < ncu ? total : ncu)), block(plan.waves * 64);
     const bool cin1 = a.Cin == 1;
-    const int ept = sinc_conv_ept(a);
+    const int ept = sinc_conv_ept(a, plan.waves);
     if (ept > 48 || (cin1 && ept > 8)) return hipErrorInvalidValue;   // uvad_sincnet_configure rejects these geometries
-#define UVAD_SINC_LAUNCH(NT_, C1_, EPT_)                                                                                   \
+#define UVAD_SINC_LAUNCH(NT_, C1_, EPT_, W_)                                                                               \
     {                                                                                                                      \
-        auto k = conv_pool_kernel<NT_, C1_, EPT_>;                                                                         \
+        auto k = conv_pool_kernel<NT_, C1_, EPT_, W_>;                                                                     \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                     \
         hipLaunchKernelGGL(k, grid, block, lds, s, a);                                                                     \
     }
-    if (cin1) {
-        if (NT == 3) UVAD_SINC_LAUNCH(3, true, 8) else UVAD_SINC_LAUNCH(2, true, 8)
+    if (cin1 && plan.waves == 8) {
+        if (NT == 3) UVAD_SINC_LAUNCH(3, true, 8, 8) else UVAD_SINC_LAUNCH(2, true, 8, 8)
+    } else if (cin1) {
+        if (NT == 3) UVAD_SINC_LAUNCH(3, true, 8, 3) else UVAD_SINC_LAUNCH(2, true, 8, 3)
+    } else if (plan.waves == 4) {
+        if (ept <= 32) { if (NT == 3) UVAD_SINC_LAUNCH(3, false, 32, 4) else UVAD_SINC_LAUNCH(2, false, 32, 4) }
+        else { if (NT == 3) UVAD_SINC_LAUNCH(3, false, 48, 4) else UVAD_SINC_LAUNCH(2, false, 48, 4) }
     } else if (ept <= 32) {
-        if (NT == 3) UVAD_SINC_LAUNCH(3, false, 32) else UVAD_SINC_LAUNCH(2, false, 32)
+        if (NT == 3) UVAD_SINC_LAUNCH(3, false, 32, 3) else UVAD_SINC_LAUNCH(2, false, 32, 3)
     } else {
-        if (NT == 3) UVAD_SINC_LAUNCH(3, false, 48) else UVAD_SINC_LAUNCH(2, false, 48)
+        if (NT == 3) UVAD_SINC_LAUNCH(3, false, 48, 3) else UVAD_SINC_LAUNCH(2, false, 48, 3)
     }
 #undef UVAD_SINC_LAUNCH
     return hipGetLastError();
 }
 
-hipError_t launch_norm_finalize(const float *partials, int B, int ntiles, int NW, int C, int L, const float *gamma, const float *beta, float eps,
-                                float *scale, float *shift, hipStream_t s) {
-    hipLaunchKernelGGL(norm_finalize_kernel, dim3(B), dim3(128), 0, s, partials, ntiles, NW, C, L, gamma, beta, eps, scale, shift);
+hipError_t launch_norm_finalize(const float *partials, int B, int ntiles, int pt, int phases, int NW, int C, int L, const float *gamma,
+                                const float *beta, float eps, float *scale, float *shift, hipStream_t s) {
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(B), dim3(128), 0, s, partials, ntiles, pt, phases, NW, C, L, gamma, beta, eps, scale, shift);
     return hipGetLastError();
 }
 

@@ -135,7 +135,7 @@ WsLayout carve(const uvad_ctx *c, int B, int64_t T) {
 
 // SincNet stage geometry and workspace for B waveforms of S samples.
 struct SincLayout {
-    int Cin[3], Cout[3], Kw[3], stride[3], NW[3];
+    int Cin[3], Cout[3], Kw[3], stride[3], NW[3], pt[3], phases[3];
     int64_t Lin[3], Lconv[3], Lpool[3];
     int ntiles[3];
     size_t off_s0 = 0, off_P[3] = {0, 0, 0}, off_part[3] = {0, 0, 0}, off_sc[3] = {0, 0, 0}, total = 0;
@@ -153,7 +153,13 @@ SincLayout sinc_carve(const uvad_ctx *c, int B, int64_t S) {
         l.Lin[i] = L;
         l.Lconv[i] = L >= kw[i] ? (L - kw[i]) / l.stride[i] + 1 : 0;
         l.Lpool[i] = l.Lconv[i] / 3;
-        l.ntiles[i] = (int)((l.Lpool[i] + 31) / 32);
+        {   // workgroup shape of the stage (sincnet.hip): pooled outputs per tile and statistics groups per tile
+            SincConvArgs a{};
+            a.Cin = cin[i]; a.Cout = cout[i]; a.Kw = kw[i]; a.stride = l.stride[i]; a.Ktot = cin[i] * kw[i]; a.Kp = (a.Ktot + 7) / 8 * 8;
+            const SincConvPlan plan = sinc_conv_plan(a);
+            l.pt[i] = plan.pt; l.phases[i] = plan.phases;
+        }
+        l.ntiles[i] = (int)((l.Lpool[i] + l.pt[i] - 1) / l.pt[i]);
         if (l.Lpool[i] <= 0) l.ok = false;
         L = l.Lpool[i];
     }
@@ -161,7 +167,7 @@ SincLayout sinc_carve(const uvad_ctx *c, int B, int64_t S) {
     l.off_s0 = o; o += align_up((size_t)2 * B * sizeof(float));
     for (int i = 0; i < 3; ++i) {
         l.off_P[i] = o; o += align_up((size_t)B * l.Cout[i] * (size_t)(l.ok ? l.Lpool[i] : 0) * sizeof(float));
-        l.off_part[i] = o; o += align_up((size_t)B * (size_t)(l.ok ? l.ntiles[i] : 0) * l.NW[i] * 2 * sizeof(float));
+        l.off_part[i] = o; o += align_up((size_t)B * (size_t)(l.ok ? l.ntiles[i] : 0) * l.phases[i] * l.NW[i] * 2 * sizeof(float));
         l.off_sc[i] = o; o += align_up((size_t)2 * B * l.Cout[i] * sizeof(float));
     }
     l.total = o;
@@ -427,9 +433,10 @@ int uvad_sincnet_configure(uvad_ctx *c, const uvad_sincnet_cfg *q) {
     for (int i = 0; i < 3; ++i) {
         SincConvArgs a{};
         a.Cin = cin[i]; a.Kw = kw[i]; a.stride = i == 0 ? q->stride : 1; a.Ktot = cin[i] * kw[i]; a.Kp = (a.Ktot + 7) / 8 * 8;
-        if (sinc_conv_lds_bytes(a, (cout[i] + 31) / 32) > (size_t)160 * 1024)
+        a.Cout = cout[i];
+        if (sinc_conv_lds_bytes(a, (cout[i] + 31) / 32, 3) > (size_t)160 * 1024)
             return fail(c, UVAD_E_UNSUPPORTED, "SincNet stage does not fit the 160 KiB LDS (filter matrix is LDS-resident)");
-        if (sinc_conv_ept(a) > (i == 0 ? 8 : 48))
+        if (sinc_conv_ept(a, 3) > (i == 0 ? 8 : 48))
             return fail(c, UVAD_E_UNSUPPORTED, "SincNet stage input window too large for the register-prefetched staging");
     }
     c->sc = *q;
@@ -474,7 +481,7 @@ static int sincnet_impl(uvad_ctx *c, const float *d_wav, int B, int64_t S, float
         a.Lconv = (int)l.Lconv[i]; a.Lpool = (int)l.Lpool[i]; a.ntiles = l.ntiles[i];
         a.out = P; a.partials = part; a.B = B; a.n_cu = c->n_cu;
         HIPCHK(c, launch_sinc_conv(a, s));
-        HIPCHK(c, launch_norm_finalize(part, B, l.ntiles[i], l.NW[i], l.Cout[i], (int)l.Lpool[i], c->sn_g[i], c->sn_b[i], q.eps, sc,
+        HIPCHK(c, launch_norm_finalize(part, B, l.ntiles[i], l.pt[i], l.phases[i], l.NW[i], l.Cout[i], (int)l.Lpool[i], c->sn_g[i], c->sn_b[i], q.eps, sc,
                                        sc + (size_t)B * l.Cout[i], s));
         in = P; in_scale = sc; in_shift = sc + (size_t)B * l.Cout[i];
     }

@@ -117,19 +117,21 @@ struct SincConvArgs {
     const float *Wt2;                                      // [Kp][NW]: W^T, zero padded (NW = 32*ceil(Cout/32))
     const float *bias;                                     // [NW] zero padded
     int Kw, stride, Ktot, Kp, Cout, do_abs;                // Ktot = Cin*Kw, Kp = Ktot rounded up to a multiple of 8
-    int Lconv, Lpool, ntiles;                              // ntiles = ceil(Lpool / 32)
+    int Lconv, Lpool, ntiles;                              // ntiles = ceil(Lpool / plan.pt)
     float *out;                                            // [B][Cout][Lpool] pooled, before the norm
-    float *partials;                                       // [B][ntiles][NW][2] (sum, M2 about the tile mean) of the pooled tile
+    float *partials;                                       // [B][ntiles][plan.phases][NW][2] (sum, M2 about the group mean) per statistics group
     int B;
     int n_cu;                                              // compute units of the device (persistent grid size); 0 = 256
 };
 hipError_t launch_wav_stats(const float *wav, int B, long long S, long long row_stride, const float *gamma, const float *beta, float eps,
                             float *scale, float *shift, hipStream_t s);
+struct SincConvPlan { int waves, pt, phases; };            // waves per workgroup, pooled outputs per tile, statistics groups per tile
+SincConvPlan sinc_conv_plan(const SincConvArgs &a);        // needs Cin, Cout, Kw, stride, Kp
 hipError_t launch_sinc_conv(const SincConvArgs &a, hipStream_t s);
-size_t sinc_conv_lds_bytes(const SincConvArgs &a, int NT);
-int sinc_conv_ept(const SincConvArgs &a);   // window elements per thread held in registers (<= 8 single-channel, <= 48 otherwise)
-hipError_t launch_norm_finalize(const float *partials, int B, int ntiles, int NW, int C, int L, const float *gamma, const float *beta, float eps,
-                                float *scale, float *shift, hipStream_t s);
+size_t sinc_conv_lds_bytes(const SincConvArgs &a, int NT, int waves);
+int sinc_conv_ept(const SincConvArgs &a, int waves);   // window elements per thread held in registers (<= 8 single-channel, <= 48 otherwise)
+hipError_t launch_norm_finalize(const float *partials, int B, int ntiles, int pt, int phases, int NW, int C, int L, const float *gamma,
+                                const float *beta, float eps, float *scale, float *shift, hipStream_t s);
 hipError_t launch_sinc_out(const float *P, const float *scale, const float *shift, int B, int C, int L, float slope, float *feats, int ldf,
                            hipStream_t s);
 
