@@ -9,7 +9,9 @@ reference) on the named frame shape.
 Workload (config.workload = BASELINE configs[1]): per GPU, B=256 utterances x 10 s of synthetic
 16 kHz audio, 25 ms / 10 ms frames, 64-bin log-mel (Hamming) + PyanNet2 classifier; a "step" is
 one pass of the whole hot path (uvad_forward: PCM resident in HBM -> per-frame logits in HBM) over
-that batch.  N GPUs = N independent shards of 256 utterances (weak scaling, no data-path
+that batch.  The K steps are submitted alternately to two contexts / HIP streams (two steps in flight; every step
+does all of its work, see main()); --in-flight 1 submits them strictly one after the other (reported as the extra
+object "sequential").  N GPUs = N independent shards of 256 utterances (weak scaling, no data-path
 collective; utterance ids are disjoint across ranks).  value = frames all ranks processed / max
 over ranks of the time for exactly K steps bracketed by barrier + synchronize.
 
@@ -55,7 +57,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU (default = BASELINE cfg 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra two-batches-in-flight measurement")
+    ap.add_argument("--in-flight", type=int, default=2, help="steps in flight (1 = strictly sequential submission, 2 = default)")
+    ap.add_argument("--no-sequential", action="store_true", help="skip the extra strictly sequential measurement")
     ap.add_argument("--no-sincnet", action="store_true", help="skip the extra PyanNet (SincNet front end) measurement")
     args = ap.parse_args()
 
@@ -81,30 +84,80 @@ def main():
     pcm = synth_pcm_device(B, S, seed=42, device=dev, first=rank * B)   # disjoint utterance ids per rank
     T = rt.num_frames(S)
 
+    # Two steps in flight: the K steps are submitted alternately to two contexts (own weights copy, workspace and HIP
+    # stream each).  Every step is one complete uvad_forward over the batch; only the submission order of INDEPENDENT
+    # steps changes: while one step sits in its latency-bound recurrence (128 of the 256 CUs at B=256) the other
+    # step's feature kernel and projections run on the idle CUs.  --in-flight 1 gives the strictly sequential loop.
+    from uvad_amd.runtime import VadRuntime
+    n_fly = max(1, min(args.in_flight, 2))
+    rts = [rt]
+    for _ in range(n_fly - 1):
+        r2 = VadRuntime(device=dev, fbank=model._fbank_cfg,
+                        model={"encoding_dim": model.encoding_dim, "lstm": model.hparams.lstm, "linear": model.hparams.linear})
+        r2.load_state_dict(model.state_dict())
+        rts.append(r2)
+    # HIP streams share a small pool of hardware queues and two streams on one queue serialise (which pairs collide
+    # depends on creation order: tools/overlap_probe.py), so the pair used is picked by a short untimed calibration.
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_fly)]
+    if n_fly == 2:
+        cand = streams + [torch.cuda.Stream(device=dev) for _ in range(4)]
+        best = None
+        for i, j in ((0, 1), (2, 3), (4, 5), (1, 2), (3, 4)):
+            for rep in range(2):   # first pass warms the pair up
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for k in range(4):
+                    with torch.cuda.stream(cand[(i, j)[k & 1]]):
+                        rts[k & 1].forward(pcm, want_probs=False)
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, i, j)
+        streams = [cand[best[1]], cand[best[2]]]
+        log(f"stream pair ({best[1]}, {best[2]}) of the candidates: {best[0] / 4 * 1e3:.2f} ms per step in calibration")
+
+    def submit(k):
+        i = k % n_fly
+        with torch.cuda.stream(streams[i]):
+            return rts[i].forward(pcm, want_probs=False)
+
     log(f"rank {rank}/{world}: inputs ready (B={B}, T={T}); warmup")
-    for _ in range(args.warmup):
-        rt.forward(pcm, want_probs=False)
+    for k in range(args.warmup):
+        submit(k)
     torch.cuda.synchronize(dev)
-    log("timed region")
-    rt.set_timing(True)
+    log(f"timed region ({n_fly} step(s) in flight)")
+    live_events = os.environ.get("UVAD_BENCH_NOTIMING") is None   # diagnostic switch: stage events off
+    for r in rts:
+        r.set_timing(live_events)
     acc = {"fbank": 0.0, "proj": 0.0, "recurrent": 0.0, "head": 0.0, "total": 0.0}
+    n_acc = 0
     torch.cuda.synchronize(dev)
     udist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        logits, _ = rt.forward(pcm, want_probs=False)
-        for k, v in rt.timing_ms().items():     # waits on this step's last event only
-            acc[k] += v
+    for k in range(args.steps):
+        if k >= n_fly and live_events:   # stage times of the step this context ran last (waits for THAT step only; the other is in flight)
+            for name, v in rts[k % n_fly].timing_ms().items():
+                acc[name] += v
+            n_acc += 1
+        logits, _ = submit(k)
     torch.cuda.synchronize(dev)
     udist.barrier()
     elapsed = time.perf_counter() - t0
-    rt.set_timing(False)
+    for i in range(min(n_fly, args.steps) if live_events else 0):
+        for name, v in rts[i].timing_ms().items():
+            acc[name] += v
+        n_acc += 1
+    for r in rts:
+        r.set_timing(False)
     elapsed = udist.max_over_ranks(elapsed, device=dev if world > 1 else None)
     log(f"{args.steps} steps in {elapsed:.3f} s")
+    if not live_events:
+        log(f"diagnostic run without stage events: {world * B * T * args.steps / elapsed / 1e6:.2f} M frames/s")
+        return
 
     frames_total = world * B * T * args.steps
     value = frames_total / elapsed
-    ms = {k: v / args.steps for k, v in acc.items()}
+    ms = {k: v / max(n_acc, 1) for k, v in acc.items()}
     proj_f, rec_f, head_f = classifier_flops_per_frame(N_MELS)
     frames_step = B * T
     stage = {
@@ -136,6 +189,9 @@ def main():
     roofline = {"kernel": kern, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                 "traffic_source": traffic_src, "avg_launch_ms": dur_ms, "flops_per_launch": flops_launch}
+    if n_fly > 1:
+        roofline["note"] = ("launch duration measured while the other in-flight step's kernels share the GPU (this kernel owns 128 of the "
+                            "256 CUs at B=256); see sequential.roofline for the same launch with the GPU to itself")
 
     out = {
         "metric": "audio frames/sec (log-mel + PyanNet2 VAD forward); per-frame logit max-abs-err vs CPU ref",
@@ -146,11 +202,14 @@ def main():
                                "PyanNet2 4xBiLSTM(128)+2xFC classifier (BASELINE configs[1])",
                    "utterances_per_gpu": B, "frames_per_utterance": T, "n_mels": N_MELS, "sharding": f"utterance-shard x{world}"},
         "roofline": roofline, "stages": stage,
-        "classifier_frac_of_f32_mfma_peak": frames_step * (proj_f + rec_f + head_f) / ((ms["total"] - ms["fbank"]) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+        "classifier_frac_of_f32_mfma_peak": frames_step * (proj_f + rec_f + head_f) / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
     }
+    out["config"]["steps_in_flight"] = n_fly
+    out["stages_note"] = ("per-stage HIP-event times of one step, measured inside the timed region on that step's own stream; with 2 steps "
+                          "in flight the stages of the two steps overlap, so they do not add up to ms_per_step")
 
-    if not args.no_pipelined:
-        out["pipelined"] = pipelined_throughput(model, dev, pcm, args.steps, world)
+    if n_fly > 1 and not args.no_sequential:
+        out["sequential"] = sequential_latency(rts[0], dev, pcm, min(args.steps, 10), world)
     if rank == 0 and world == 1 and not args.no_sincnet:
         out["pyannet_sincnet"] = sincnet_throughput(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -160,38 +219,34 @@ def main():
     udist.barrier()
 
 
-def pipelined_throughput(model, dev, pcm, steps, world):
-    """Extra, NOT the headline value: the same K steps with TWO batches in flight (two contexts, two HIP streams,
-    two workspaces).  At B=256 the recurrence of one batch occupies 128 of the 256 CUs and is latency-bound, so
-    the projections / features of the other batch run beside it.  Every step does all of its work; only the
-    order in which independent steps are submitted changes."""
-    import uvad_amd
+def sequential_latency(rt, dev, pcm, steps, world):
+    """Extra, NOT the headline value: the same step submitted strictly one after the other on one stream (what a single
+    caller without a second context sees): latency of one step and the throughput that goes with it."""
     from uvad_amd import dist as udist
-    from uvad_amd.runtime import VadRuntime
-    cfg = {"encoding_dim": model.encoding_dim, "lstm": model.hparams.lstm, "linear": model.hparams.linear}
-    rts, streams = [], []
-    for _ in range(2):
-        r = VadRuntime(device=dev, fbank=model._fbank_cfg, model=cfg)
-        r.load_state_dict(model.state_dict())
-        rts.append(r)
-        streams.append(torch.cuda.Stream(device=dev))
-    for i in range(2):
-        with torch.cuda.stream(streams[i]):
-            rts[i].forward(pcm, want_probs=False)
+    rt.forward(pcm, want_probs=False)
     torch.cuda.synchronize(dev)
     udist.barrier()
     t0 = time.perf_counter()
-    for k in range(steps):
-        with torch.cuda.stream(streams[k & 1]):
-            rts[k & 1].forward(pcm, want_probs=False)
+    for _ in range(steps):
+        rt.forward(pcm, want_probs=False)
     torch.cuda.synchronize(dev)
     udist.barrier()
     dt = udist.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 else None)
-    frames = world * pcm.shape[0] * rts[0].num_frames(pcm.shape[1]) * steps
-    for r in rts:
-        r.close()
-    return {"value": frames / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "batches_in_flight": 2,
-            "note": "same K steps, two independent batches in flight on two HIP streams; not the headline value"}
+    frames = world * pcm.shape[0] * rt.num_frames(pcm.shape[1]) * steps
+    # the recurrent kernel's launch duration when it has the GPU to itself (3 more steps with stage events)
+    rt.set_timing(True)
+    rec = 0.0
+    for _ in range(3):
+        rt.forward(pcm, want_probs=False)
+        rec += rt.timing_ms()["recurrent"]
+    rt.set_timing(False)
+    _, rec_f, _ = classifier_flops_per_frame(N_MELS)
+    launch_ms = rec / 3 / 4
+    tf = pcm.shape[0] * rt.num_frames(pcm.shape[1]) * rec_f / 4 / (launch_ms * 1e-3) / 1e12
+    return {"value": frames / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps_in_flight": 1,
+            "roofline": {"kernel": "lstm_rec_kernel<128>", "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": launch_ms},
+            "note": "same step, one at a time on one stream; not the headline value"}
 
 
 def sincnet_throughput(dev, B=256, S=80000, reps=5):

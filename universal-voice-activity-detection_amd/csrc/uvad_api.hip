@@ -378,7 +378,7 @@ int uvad_finalize(uvad_ctx *c) {
     if ((r = dev_upload(c, cb->data.data(), cb->data.size(), &c->cls_b))) return r;
     c->layer_ev.resize((size_t)2 * m.num_layers + 2);
     for (auto &ev : c->layer_ev) HIPCHK(c, hipEventCreate(&ev));
-    if (!c->side) HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    if (c->overlap && !c->side) HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));   // only the optional overlap path uses it (streams share few hardware queues)
     c->ovl_ev.resize((size_t)m.num_layers * 9 + 2);
     for (auto &ev : c->ovl_ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     c->sinc_ready = false;
