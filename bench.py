@@ -89,7 +89,7 @@ def main():
     # steps changes: while one step sits in its latency-bound recurrence (128 of the 256 CUs at B=256) the other
     # step's feature kernel and projections run on the idle CUs.  --in-flight 1 gives the strictly sequential loop.
     from uvad_amd.runtime import VadRuntime
-    n_fly = max(1, min(args.in_flight, 2))
+    n_fly = max(1, min(args.in_flight, 4))
     rts = [rt]
     for _ in range(n_fly - 1):
         r2 = VadRuntime(device=dev, fbank=model._fbank_cfg,
@@ -99,22 +99,23 @@ def main():
     # HIP streams share a small pool of hardware queues and two streams on one queue serialise (which pairs collide
     # depends on creation order: tools/overlap_probe.py), so the pair used is picked by a short untimed calibration.
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_fly)]
-    if n_fly == 2:
+    if n_fly >= 2:
         cand = streams + [torch.cuda.Stream(device=dev) for _ in range(4)]
         best = None
-        for i, j in ((0, 1), (2, 3), (4, 5), (1, 2), (3, 4)):
-            for rep in range(2):   # first pass warms the pair up
+        for first in range(len(cand) - n_fly + 1):
+            sel = list(range(first, first + n_fly))
+            for rep in range(2):   # first pass warms the selection up
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
-                for k in range(4):
-                    with torch.cuda.stream(cand[(i, j)[k & 1]]):
-                        rts[k & 1].forward(pcm, want_probs=False)
+                for k in range(2 * n_fly):
+                    with torch.cuda.stream(cand[sel[k % n_fly]]):
+                        rts[k % n_fly].forward(pcm, want_probs=False)
                 torch.cuda.synchronize(dev)
-                dt = time.perf_counter() - t0
+                dt = (time.perf_counter() - t0) / (2 * n_fly)
             if best is None or dt < best[0]:
-                best = (dt, i, j)
-        streams = [cand[best[1]], cand[best[2]]]
-        log(f"stream pair ({best[1]}, {best[2]}) of the candidates: {best[0] / 4 * 1e3:.2f} ms per step in calibration")
+                best = (dt, sel)
+        streams = [cand[i] for i in best[1]]
+        log(f"streams {best[1]} of the candidates: {best[0] * 1e3:.2f} ms per step in calibration")
 
     def submit(k):
         i = k % n_fly
