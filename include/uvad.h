@@ -199,10 +199,14 @@ int uvad_forward_wav(uvad_ctx *, const float *d_wav, int B, int64_t S, float *d_
 
 /* Which kernel runs the time-parallel contractions (input projections, feed-forward layers):
  *   0  exact f32: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain, bit-compatible with f32 FMA arithmetic;
- *   1  (default) f32-accurate on the bf16 matrix cores: operands split exactly into three bf16 pieces,
- *      six v_mfma_f32_32x32x16_bf16 per product term set, f32 accumulation (2.7x the f32 MFMA rate;
- *      dropped terms <= 2^-23 relative).  Both are held to the same 1e-4 logit bound by the tests.
- * The environment variable UVAD_GEMM=f32 selects 0 at uvad_create. */
+ *   1  f32-accurate on the bf16 matrix cores: operands split exactly into three bf16 pieces, six
+ *      v_mfma_f32_32x32x16_bf16 per product term set, f32 accumulation (dropped terms <= 2^-23 relative);
+ *   2  (default) f32-accurate on the f16 matrix cores: operands split into two f16 pieces (the low one scaled by
+ *      2^11), three v_mfma_f32_32x32x16_f16 per product term set in two f32 accumulator sets (dropped term
+ *      <= 2^-22 relative, below the rounding noise of the f32 accumulation): half the matrix-core work of mode 1.
+ *      Needs |weight| < 65504; a context whose weights do not fit runs mode 1 instead.
+ * All three are held to the same 1e-4 logit bound by the tests.  The environment variable UVAD_GEMM = f32 | bf16x6 |
+ * f16x3 selects the mode at uvad_create. */
 int uvad_set_gemm_mode(uvad_ctx *, int mode);
 
 /* Per-stage device timing of the most recent uvad_forward/uvad_classify made with timing enabled

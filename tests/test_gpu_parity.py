@@ -292,17 +292,50 @@ def test_streaming_rejects_bidirectional_and_unreset_state():
     assert ei.value.code == -5
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x6"])
-def test_both_gemm_modes_meet_the_logit_bound(mode):
-    g, sd, case = load_golden("pyannet2_f64_T1000")
+@pytest.mark.parametrize("mode", ["f32", "bf16x6", "f16x3"])
+@pytest.mark.parametrize("name", ["pyannet2_f64_T1000", "pyannet2_f80_T500", "pyannet2_f64_T3000"])
+def test_all_gemm_modes_meet_the_logit_bound(mode, name):
+    g, sd, case = load_golden(name)
     dev = torch.device("cuda:0")
     m = _model(case, sd, dev)
     rt = m.runtime(dev)
     rt.set_gemm_mode(mode)
     logits, _ = m.forward_logits(torch.from_numpy(g["feats"]).to(dev))
     err = np.abs(logits.cpu().numpy() - g["logits"]).max()
-    print(f"gemm mode {mode}: logit err vs reference golden {err:.2e}")
+    print(f"gemm mode {mode}, {name}: logit err vs reference golden {err:.2e}")
     assert err < LOGIT_TOL
+
+
+def test_f16x3_gemm_is_f32_accurate_and_handles_awkward_operands():
+    """The 2-way f16 split against the exact f32-MFMA kernel on one projection-shaped product with operands spanning
+    the magnitudes of the path (tiny activations, log-mel-sized features, weights x4): relative error of the same order
+    as f32 accumulation noise; a weight outside the f16 range makes the context fall back to the bf16 split."""
+    import uvad_amd
+    from oracle import torch_ref as tr
+    dev = torch.device("cuda:0")
+    sd = tr.seeded_state_dict(64, 128, 1, False, lin_layers=0, seed=5, scale=4.0)
+    m = uvad_amd.PyanNet2(lstm={"num_layers": 1, "bidirectional": False}, linear={"num_layers": 0}, encoding_dim=64)
+    m.build()
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(8, 300, 64, generator=g) * 4.0 - 8.0
+    feats[:, :, :8] *= 1e-4                 # tiny columns
+    feats[:, :, 8:16] = feats[:, :, 8:16] * 3.0   # up to ~ +-40
+    out = {}
+    for mode in ("f32", "f16x3", "bf16x6"):
+        m.runtime(dev).set_gemm_mode(mode)
+        out[mode], _ = m.forward_logits(feats.to(dev))
+    torch.cuda.synchronize()
+    e16 = (out["f16x3"] - out["f32"]).abs().max().item()
+    ebf = (out["bf16x6"] - out["f32"]).abs().max().item()
+    print(f"single layer: f16x3 vs exact f32 MFMA {e16:.2e}, bf16x6 vs exact {ebf:.2e}")
+    assert e16 < 2e-5 and ebf < 2e-5
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["lstm.weight_ih_l0"][0, 0] = 1.0e5     # outside the f16 range
+    m.load_state_dict(sd2)
+    big, _ = m.forward_logits(feats.to(dev))     # runs (bf16 split) and stays finite
+    assert torch.isfinite(big).all()
 
 
 def test_label_runs_on_device_equal_the_host_walk_and_the_oracle():

@@ -18,8 +18,12 @@ m.attach_fbank(uvad_amd.FbankConfig(num_filters=F, window_type="hamming")); m = 
 rt = m.runtime(dev)
 pcm = synth_pcm_device(B, 160000, seed=42, device=dev)
 feats = rt.fbank(pcm)
-gl, _ = rt.classify(feats, want_probs=False)
-gl = gl.cpu().numpy()
+gls = {}
+for mode in ("f32", "bf16x6", "f16x3"):
+    rt.set_gemm_mode(mode)
+    g_, _ = rt.classify(feats, want_probs=False)
+    gls[mode] = g_.cpu().numpy()
+gl = gls["f16x3"]
 cpu = tr.TorchPyanNet2(F); cpu.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
 fc = feats.cpu()
 rl = cpu(fc)[0].numpy()
@@ -27,4 +31,6 @@ sd = {k: v.cpu().numpy() for k, v in m.state_dict().items()}
 ol, _ = co.classify(sd, co.ModelCfg(F, 128, 4, 1, 128, 2, 0.01), fc.numpy())
 print(f"B={B} scale={scale}: logits range {ol.min():.2f}..{ol.max():.2f}")
 print(f"  |GPU - oracle(f64 acc)| = {np.abs(gl-ol).max():.2e}   |CPU fp32 - oracle| = {np.abs(rl-ol).max():.2e}   |GPU - CPU fp32| = {np.abs(gl-rl).max():.2e}")
+for mode, g_ in gls.items():
+    print(f"  gemm {mode:7s}: |GPU - oracle| max {np.abs(g_-ol).max():.2e} mean {np.abs(g_-ol).mean():.2e}   |GPU - CPU fp32| max {np.abs(g_-rl).max():.2e} mean {np.abs(g_-rl).mean():.2e}")
 print(f"  mean abs: GPU-oracle {np.abs(gl-ol).mean():.2e}  CPU-oracle {np.abs(rl-ol).mean():.2e}")

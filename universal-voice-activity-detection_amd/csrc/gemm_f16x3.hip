@@ -1,0 +1,278 @@
+// gemm_f16x3.hip -- f32-accurate GEMM on the f16 matrix cores ("f16x3"): same contract as gemm.hip
+// (C = act(A * W^T + b), A f32 in HBM) with HALF the matrix-core work of gemm_split.hip's bf16x6.
+//
+// Each f32 operand is split into two f16 pieces (11 + 11 mantissa bits, the low piece pre-scaled by 2^11 so that
+// it never falls into the f16 subnormal range):
+//     x ~= x1 + x2 * 2^-11,   x1 = f16(x), x2 = f16((x - x1) * 2^11)          (residual <= 2^-22 |x|)
+// and the product keeps the three leading terms in two f32 accumulator sets:
+//     hi += a1*w1;   lo += a1*w2 + a2*w1;   a*w ~= hi + lo * 2^-11             (dropped: a2*w2, <= 2^-22 relative)
+// f16 x f16 products are exact in f32 and v_mfma_f32_32x32x16_f16 accumulates in f32.  The split error (rms 1.2e-7
+// relative on K = 256 dot products of the path's operands, tools measurement in profiles/README.md) is below the
+// rounding noise of the f32 accumulation itself (4e-7), so the result carries f32-level error; the tests hold it to
+// the same 1e-4 logit bound as the exact kernel.  Operand range: |x| < 65504 (activations and weights of this path
+// are O(1); log-mel features are within +-30) -- uvad_finalize rejects weights outside it.
+// Weights are split once on the host; activations on the fly while they are staged into LDS.
+//
+// Tile: 128x128 per 256-thread workgroup, 2x2 waves x 2x2 tiles of 32x32 (x 2 accumulator sets), K-step 32.
+// LDS: 2 planes x (A, W) x 128 rows x 40 f16 (80-byte rows: conflict-free ds_read_b128 fragments).
+#include "uvad_internal.h"
+
+namespace uvad {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, LDH = 40;   // LDH: LDS row stride in f16 elements
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+
+__device__ __forceinline__ const float *a_row_ptr(const GemmArgs &a, int m, int r0, int rend) {
+    if (m >= rend) return a.A + (a.a_mode == 1 ? (size_t)0 : (size_t)r0 * a.lda);
+    if (a.a_mode != 1) return a.A + (size_t)m * a.lda;
+    const int per_tile = a.T * SEQ_TILE;
+    const int tile = m / per_tile, rem = m - tile * per_tile;
+    const int t = rem / SEQ_TILE, j = rem - t * SEQ_TILE;
+    const int b = tile * SEQ_TILE + j;
+    if (b >= a.B) return a.A;
+    return a.A + ((size_t)b * a.T + t) * a.lda;
+}
+
+// (x, y) -> two packed f16 pairs: hi = (f16(x), f16(y)), lo = (f16((x - hi.x) * 2^11), f16((y - hi.y) * 2^11)).
+// The residual is exact in f32 (Sterbenz), round-to-nearest conversions.
+__device__ __forceinline__ void split2_pair(float x, float y, unsigned &p1, unsigned &p2) {
+    const f16x2 h = {(_Float16)x, (_Float16)y};
+    const float rx = (x - (float)h.x) * 2048.0f, ry = (y - (float)h.y) * 2048.0f;
+    const f16x2 l = {(_Float16)rx, (_Float16)ry};
+    p1 = __builtin_bit_cast(unsigned, h);
+    p2 = __builtin_bit_cast(unsigned, l);
+}
+
+#ifdef UVAD_GS_STAMP   // diagnostic build (tools/gemm_ablate.hip): cycle shares of one K-step
+#define GS_STAMP(i)                                                                        \
+    {                                                                                      \
+        unsigned long long t_;                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        gs_acc[i] += t_ - gs_prev;                                                         \
+        gs_prev = t_;                                                                      \
+    }
+#else
+#define GS_STAMP(i)
+#endif
+
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs a, int mt, int nt) {
+#ifdef UVAD_GS_STAMP
+    unsigned long long gs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gs_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gs_prev)::"memory");
+#endif
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * LDH];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * LDH];
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int m_tile = (idx / nt) * 8 + xcd, n_tile = idx % nt;
+    if (m_tile >= mt) return;
+    int R0 = m_tile * BM, Rend = a.M;
+    if (a.a_mode == 2) {   // time window of the tile-major matrix (see GemmArgs)
+        const int nblk = (a.win_tc * SEQ_TILE + BM - 1) / BM;
+        const int tile = m_tile / nblk, blk = m_tile - tile * nblk;
+        R0 = (tile * a.T + a.win_t0) * SEQ_TILE + blk * BM;
+        Rend = (tile * a.T + a.win_t0 + a.win_tc) * SEQ_TILE;
+    }
+    const int C0 = n_tile * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // A staging: 8 float4 per 32-float row, 32 rows per pass, 4 passes
+    const int srow = tid >> 3, skq = tid & 7;
+    const float *ap0 = a_row_ptr(a, R0 + srow, R0, Rend) + skq * 4;
+    const float *ap1 = a_row_ptr(a, R0 + srow + 32, R0, Rend) + skq * 4;
+    const float *ap2 = a_row_ptr(a, R0 + srow + 64, R0, Rend) + skq * 4;
+    const float *ap3 = a_row_ptr(a, R0 + srow + 96, R0, Rend) + skq * 4;
+    // W staging (pre-split f16 planes [2][N][ldw]): thread = (row, 16-element half)
+    const int brow = tid >> 1, bhalf = tid & 1;
+    const int nrow = C0 + brow < a.N ? C0 + brow : 0;
+    const size_t plane = (size_t)a.N * a.ldw;
+    const unsigned short *wp = a.Wsplit16 + (size_t)nrow * a.ldw + bhalf * 16;
+
+    f32x16 acc00, acc01, acc10, acc11, lo00, lo01, lo10, lo11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; lo00[r] = 0.f; lo01[r] = 0.f; lo10[r] = 0.f; lo11[r] = 0.f; }
+
+    // A is streamed from HBM (every K-step of a row is a fresh 128-byte line: full memory latency), so
+    // its loads run TWO K-steps ahead (ra* = next step, rn* = the one after); the pre-split weights are
+    // L2-resident and run one step ahead.
+    float4 ra0, ra1, ra2, ra3, rn0, rn1, rn2, rn3;
+    uint4 rw00, rw01, rw10, rw11;
+#define UVAD_GLOAD_A(R0_, R1_, R2_, R3_, k0)                                            \
+    {                                                                                   \
+        const int ka_ = ((k0) + skq * 4 < a.K) ? (k0) : -skq * 4;                       \
+        R0_ = *reinterpret_cast<const float4 *>(ap0 + ka_);                             \
+        R1_ = *reinterpret_cast<const float4 *>(ap1 + ka_);                             \
+        R2_ = *reinterpret_cast<const float4 *>(ap2 + ka_);                             \
+        R3_ = *reinterpret_cast<const float4 *>(ap3 + ka_);                             \
+    }
+#define UVAD_GLOAD_W(k0)                                                                \
+    {                                                                                   \
+        rw00 = *reinterpret_cast<const uint4 *>(wp + (k0));                             \
+        rw01 = *reinterpret_cast<const uint4 *>(wp + (k0) + 8);                         \
+        rw10 = *reinterpret_cast<const uint4 *>(wp + plane + (k0));                     \
+        rw11 = *reinterpret_cast<const uint4 *>(wp + plane + (k0) + 8);                 \
+    }
+    // split of the NEXT K-step's A values into packed f16 pairs (VALU only: issued in the shadow of the
+    // current step's MFMAs, 24 of every 32 cycles of a 32x32x16 MFMA leave the vector issue port free)
+    uint2 q1_0, q2_0, q1_1, q2_1, q1_2, q2_2, q1_3, q2_3;
+#define UVAD_SPLIT(RA, Q1, Q2)                                                          \
+    {                                                                                   \
+        split2_pair(RA.x, RA.y, Q1.x, Q2.x);                                            \
+        split2_pair(RA.z, RA.w, Q1.y, Q2.y);                                            \
+    }
+#define UVAD_SPLIT_ALL()                                                                \
+    {                                                                                   \
+        UVAD_SPLIT(ra0, q1_0, q2_0)                                                     \
+        UVAD_SPLIT(ra1, q1_1, q2_1)                                                     \
+        UVAD_SPLIT(ra2, q1_2, q2_2)                                                     \
+        UVAD_SPLIT(ra3, q1_3, q2_3)                                                     \
+    }
+#define UVAD_STORE_ROW(ROW, Q1, Q2)                                                     \
+    {                                                                                   \
+        *reinterpret_cast<uint2 *>(&As[0][(ROW) * LDH + skq * 4]) = Q1;                 \
+        *reinterpret_cast<uint2 *>(&As[1][(ROW) * LDH + skq * 4]) = Q2;                 \
+    }
+#define UVAD_LSTORE()                                                                   \
+    {                                                                                   \
+        UVAD_STORE_ROW(srow, q1_0, q2_0)                                                \
+        UVAD_STORE_ROW(srow + 32, q1_1, q2_1)                                           \
+        UVAD_STORE_ROW(srow + 64, q1_2, q2_2)                                           \
+        UVAD_STORE_ROW(srow + 96, q1_3, q2_3)                                           \
+        *reinterpret_cast<uint4 *>(&Bs[0][brow * LDH + bhalf * 16]) = rw00;             \
+        *reinterpret_cast<uint4 *>(&Bs[0][brow * LDH + bhalf * 16 + 8]) = rw01;         \
+        *reinterpret_cast<uint4 *>(&Bs[1][brow * LDH + bhalf * 16]) = rw10;             \
+        *reinterpret_cast<uint4 *>(&Bs[1][brow * LDH + bhalf * 16 + 8]) = rw11;         \
+    }
+
+    const int nk = (a.K + BK - 1) / BK;
+    UVAD_GLOAD_A(ra0, ra1, ra2, ra3, 0)
+    UVAD_GLOAD_W(0)
+    if (nk > 1) UVAD_GLOAD_A(rn0, rn1, rn2, rn3, BK)
+    UVAD_SPLIT_ALL()
+    UVAD_LSTORE()
+    __syncthreads();
+
+    GS_STAMP(0)   // [0] prologue: first loads, split, store, barrier
+    const int fr = lane & 31, fh = lane >> 5;
+    const int a_off = (wr * 64 + fr) * LDH + fh * 8, b_off = (wc * 64 + fr) * LDH + fh * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            ra0 = rn0; ra1 = rn1; ra2 = rn2; ra3 = rn3;   // step kt+1 (issued one iteration ago)
+            UVAD_GLOAD_W((kt + 1) * BK)
+            if (kt + 2 < nk) UVAD_GLOAD_A(rn0, rn1, rn2, rn3, (kt + 2) * BK)
+        }
+        GS_STAMP(1)   // [1] issue of the global loads
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            f16x8 fa[2][2], fb[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                fa[0][p] = *reinterpret_cast<const f16x8 *>(&As[p][a_off + s * 16]);
+                fa[1][p] = *reinterpret_cast<const f16x8 *>(&As[p][a_off + 32 * LDH + s * 16]);
+                fb[0][p] = *reinterpret_cast<const f16x8 *>(&Bs[p][b_off + s * 16]);
+                fb[1][p] = *reinterpret_cast<const f16x8 *>(&Bs[p][b_off + 32 * LDH + s * 16]);
+            }
+#define UVAD_MM(ACC, I, J, PA, PB) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[I][PA], fb[J][PB], ACC, 0, 0, 0);
+#define UVAD_THREE(HI, LO, I, J) UVAD_MM(LO, I, J, 0, 1) UVAD_MM(LO, I, J, 1, 0) UVAD_MM(HI, I, J, 0, 0)
+            UVAD_THREE(acc00, lo00, 0, 0)
+            UVAD_THREE(acc01, lo01, 0, 1)
+            UVAD_THREE(acc10, lo10, 1, 0)
+            UVAD_THREE(acc11, lo11, 1, 1)
+        }
+        UVAD_SPLIT_ALL()   // VALU work of the next step (unconditional: same basic block as the MFMAs, so it can be
+                           // scheduled between them; on the last step it splits stale registers nobody stores)
+        // [8 fragment reads][12 x (1 MFMA + 4 VALU)] per 16-deep half step
+#pragma unroll
+        for (int hs = 0; hs < BK / 16; ++hs) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+        }
+        GS_STAMP(2)   // [2] fragment reads + 48 MFMAs (+ split of the next step)
+        __syncthreads();
+        GS_STAMP(3)   // [3] barrier after compute
+        // unconditional (also after the last step, where it stores stale data nobody reads): a branch here
+        // would let LLVM sink the split into it, away from the MFMAs it is meant to hide behind
+        UVAD_LSTORE()
+        GS_STAMP(4)   // [4] LDS store of the next step
+        __syncthreads();
+        GS_STAMP(5)   // [5] barrier after store
+    }
+    GS_STAMP(6)
+
+    // epilogue: as gemm.hip (C/D map of the 32x32 MFMA is dtype-independent), on hi + lo * 2^-11
+    const bool full = R0 + BM <= Rend && C0 + BN <= a.N;
+#define UVAD_EPILOGUE(ACC, LO, I, J)                                                                   \
+    {                                                                                                \
+        const int col = C0 + wc * 64 + (J) * 32 + fr;                                                \
+        const int rbase = R0 + wr * 64 + (I) * 32 + 4 * fh;                                          \
+        const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;                                \
+        float *crow = a.C + (size_t)rbase * a.ldc + col;                                             \
+        float v[16];                                                                                 \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
+            v[r] = __builtin_fmaf(LO[r], 0.00048828125f, ACC[r]) + bias;                                                                   \
+            if (a.act == 1) v[r] = v[r] >= 0.f ? v[r] : a.leaky_slope * v[r];                        \
+        }                                                                                            \
+        if (full) {                                                                                  \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r)                                           \
+                crow[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldc] = v[r];                               \
+        } else {                                                                                     \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
+                const int dr = (r & 3) + 8 * (r >> 2);                                               \
+                if (rbase + dr < Rend && col < a.N) crow[(size_t)dr * a.ldc] = v[r];                  \
+            }                                                                                        \
+        }                                                                                            \
+    }
+    UVAD_EPILOGUE(acc00, lo00, 0, 0)
+    UVAD_EPILOGUE(acc01, lo01, 0, 1)
+    UVAD_EPILOGUE(acc10, lo10, 1, 0)
+    UVAD_EPILOGUE(acc11, lo11, 1, 1)
+#ifdef UVAD_GS_STAMP
+    GS_STAMP(7)   // [7] epilogue
+    if (lane == 0 && blockIdx.x == 4000) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.C) + wave * 8;
+        for (int i = 0; i < 8; ++i) o[i] = gs_acc[i];
+    }
+#endif
+}
+
+}  // namespace
+
+// host: f32 [N][ldw] (rows already zero-padded) -> two f16 planes [2][N][ldw]; false if a weight is outside the f16 range
+bool split_weights_f16x2(const float *w, size_t n, unsigned short *out) {
+    bool ok = true;
+    for (size_t i = 0; i < n; ++i) {
+        const float x = w[i];
+        if (!(x > -65504.0f && x < 65504.0f)) ok = false;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
+        __builtin_memcpy(&out[i], &h, 2);
+        __builtin_memcpy(&out[n + i], &l, 2);
+    }
+    return ok;
+}
+
+hipError_t launch_gemm_f16x3(const GemmArgs &a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return hipSuccess;
+    if (a.ldw < gemm_padded_k(a.K) || !a.Wsplit16) return hipErrorInvalidValue;
+    const int mt = a.a_mode == 2 ? a.win_tiles * ((a.win_tc * SEQ_TILE + BM - 1) / BM) : (a.M + BM - 1) / BM;
+    const int nt = (a.N + BN - 1) / BN;
+    if (mt <= 0) return hipSuccess;
+    const int grid = ((mt + 7) / 8) * 8 * nt;
+    hipLaunchKernelGGL(gemm_f16x3_kernel, dim3(grid), dim3(256), 0, s, a, mt, nt);
+    return hipGetLastError();
+}
+
+}  // namespace uvad

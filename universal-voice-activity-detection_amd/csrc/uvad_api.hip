@@ -23,6 +23,7 @@ struct HostTensor {
 struct LayerDev {
     float *w_ih = nullptr;   // [dirs*4H (permuted: dir, unit, gate)][in]
     unsigned short *w_ih_split = nullptr;   // the same as three bf16 planes (gemm_split.hip)
+    unsigned short *w_ih_split16 = nullptr; // the same as two f16 planes (gemm_f16x3.hip)
     float *bias = nullptr;   // [dirs*4H] b_ih + b_hh, same permutation
     float *w_hh = nullptr;   // [dirs][packed register image]
     float *w_hh16 = nullptr; // [dirs][register image of the 16-sequence kernel] (H = 128)
@@ -46,8 +47,9 @@ struct uvad_ctx {
     int mel_stride = 0;
     std::vector<LayerDev> layers;
     std::vector<float *> lin_w, lin_b;
-    std::vector<unsigned short *> lin_w_split;
-    int gemm_mode = 1;   // 0: exact f32 MFMA (gemm.hip); 1: split-bf16 x6 (gemm_split.hip)
+    std::vector<unsigned short *> lin_w_split, lin_w_split16;
+    bool f16_ok = true;   // every GEMM weight fits the f16 range (gemm mode 2 is usable)
+    int gemm_mode = 2;   // 0: exact f32 MFMA (gemm.hip); 1: split-bf16 x6 (gemm_split.hip); 2: split-f16 x3 (gemm_f16x3.hip)
     // overlap of layer k+1's input projection with layer k's recurrence (side stream + events)
     int overlap = 0;     // off by default: measured neutral with the on-the-fly split GEMM (profiles/README.md); UVAD_OVERLAP=1
     hipStream_t side = nullptr;
@@ -252,7 +254,7 @@ int uvad_create(int device, const uvad_fbank_cfg *fb, const uvad_model_cfg *mode
             return fail(c, UVAD_E_ARG, "bad model configuration");
     }
     for (auto &ev : c->ev) HIPCHK(c, hipEventCreate(&ev));
-    if (const char *e = std::getenv("UVAD_GEMM")) c->gemm_mode = std::strcmp(e, "f32") == 0 ? 0 : 1;
+    if (const char *e = std::getenv("UVAD_GEMM")) c->gemm_mode = std::strcmp(e, "f32") == 0 ? 0 : std::strcmp(e, "bf16x6") == 0 ? 1 : 2;
     if (const char *e = std::getenv("UVAD_OVERLAP")) c->overlap = std::strcmp(e, "0") == 0 ? 0 : 1;
     return UVAD_OK;
 }
@@ -312,6 +314,7 @@ int uvad_finalize(uvad_ctx *c) {
         return it == c->host_w.end() ? nullptr : &it->second;
     };
     c->layers.assign(m.num_layers, LayerDev());
+    c->f16_ok = true;
     for (int k = 0; k < m.num_layers; ++k) {
         const int in = k == 0 ? m.in_dim : H * D;
         const int inp = gemm_padded_k(in);   // rows zero-padded to the GEMM's K-step
@@ -344,6 +347,11 @@ int uvad_finalize(uvad_ctx *c) {
             split_weights_bf16x3(wp.data(), wp.size(), sp.data());
             if ((r = dev_upload(c, sp.data(), sp.size(), &L.w_ih_split))) return r;
         }
+        {
+            std::vector<unsigned short> sp(2 * wp.size());
+            if (!split_weights_f16x2(wp.data(), wp.size(), sp.data())) c->f16_ok = false;
+            if ((r = dev_upload(c, sp.data(), sp.size(), &L.w_ih_split16))) return r;
+        }
         if ((r = dev_upload(c, bp.data(), bp.size(), &L.bias))) return r;
         if ((r = dev_upload(c, hh.data(), hh.size(), &L.w_hh))) return r;
         if (H == 128 && (r = dev_upload(c, hh16.data(), hh16.size(), &L.w_hh16))) return r;
@@ -351,6 +359,7 @@ int uvad_finalize(uvad_ctx *c) {
     c->lin_w.assign(m.lin_layers, nullptr);
     c->lin_b.assign(m.lin_layers, nullptr);
     c->lin_w_split.assign(m.lin_layers, nullptr);
+    c->lin_w_split16.assign(m.lin_layers, nullptr);
     int prev = H * D;
     for (int j = 0; j < m.lin_layers; ++j) {
         const HostTensor *w = get("linear." + std::to_string(j) + ".weight"), *b = get("linear." + std::to_string(j) + ".bias");
@@ -366,6 +375,11 @@ int uvad_finalize(uvad_ctx *c) {
             std::vector<unsigned short> sp(3 * wpad.size());
             split_weights_bf16x3(wpad.data(), wpad.size(), sp.data());
             if ((r = dev_upload(c, sp.data(), sp.size(), &c->lin_w_split[j]))) return r;
+        }
+        {
+            std::vector<unsigned short> sp(2 * wpad.size());
+            if (!split_weights_f16x2(wpad.data(), wpad.size(), sp.data())) c->f16_ok = false;
+            if ((r = dev_upload(c, sp.data(), sp.size(), &c->lin_w_split16[j]))) return r;
         }
         if ((r = dev_upload(c, b->data.data(), b->data.size(), &c->lin_b[j]))) return r;
         prev = m.lin_hidden;
@@ -568,7 +582,11 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
     float *Z[2] = {reinterpret_cast<float *>(base + w.off_Z[0]), reinterpret_cast<float *>(base + w.off_Z[1])};
     const int H = m.hidden, D = w.D, N4 = 4 * H * D;
     auto Gbuf = [&](int set, int d) { return reinterpret_cast<float *>(base + w.off_G[set][d]); };
-    auto run_gemm = [&](const GemmArgs &g, hipStream_t st) { return c->gemm_mode == 1 ? launch_gemm_split(g, st) : launch_gemm(g, st); };
+    // mode 2 falls back to the bf16 split when a weight does not fit the f16 range (never the case for trained VAD weights)
+    const int gmode = c->gemm_mode == 2 && !c->f16_ok ? 1 : c->gemm_mode;
+    auto run_gemm = [&](const GemmArgs &g, hipStream_t st) {
+        return gmode == 2 ? launch_gemm_f16x3(g, st) : gmode == 1 ? launch_gemm_split(g, st) : launch_gemm(g, st);
+    };
     if (c->timing && record_start) HIPCHK(c, hipEventRecord(c->ev[0], s));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     const bool overlap = w.overlap && !ss;
@@ -577,7 +595,7 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         for (int k = 0; k < m.num_layers; ++k) {
             const LayerDev &L = c->layers[k];
             GemmArgs g{};
-            g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.Wsplit = L.w_ih_split; g.bias = L.bias; g.C = G;
+            g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.Wsplit = L.w_ih_split; g.Wsplit16 = L.w_ih_split16; g.bias = L.bias; g.C = G;
             g.M = (int)w.M; g.N = N4; g.K = L.in; g.ldc = N4; g.B = B; g.T = T; g.act = 0; g.leaky_slope = 0.f;
             if (k == 0) { g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1; }
             else { g.A = Y[(k - 1) & 1]; g.lda = w.Wd; g.a_mode = 0; }
@@ -606,7 +624,7 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         {   // layer 0: one full projection of the features
             const LayerDev &L = c->layers[0];
             GemmArgs g{};
-            g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.Wsplit = L.w_ih_split; g.bias = L.bias; g.C = Gbuf(0, 0);
+            g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.Wsplit = L.w_ih_split; g.Wsplit16 = L.w_ih_split16; g.bias = L.bias; g.C = Gbuf(0, 0);
             g.M = (int)w.M; g.N = N4; g.K = L.in; g.ldc = N4; g.B = B; g.T = T; g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1;
             if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[0], s));
             HIPCHK(c, run_gemm(g, s));
@@ -637,7 +655,7 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
                     for (int d = 0; d < D; ++d) {
                         GemmArgs g{};
                         g.A = Y[k & 1] + d * H; g.lda = w.Wd; g.a_mode = 2;
-                        g.W = Ln.w_ih + d * H; g.ldw = gemm_padded_k(Ln.in); g.Wsplit = Ln.w_ih_split + d * H;
+                        g.W = Ln.w_ih + d * H; g.ldw = gemm_padded_k(Ln.in); g.Wsplit = Ln.w_ih_split + d * H; g.Wsplit16 = Ln.w_ih_split16 + d * H;
                         g.bias = d == 0 ? Ln.bias : nullptr; g.C = Gbuf(set ^ 1, d);
                         g.M = (int)w.M; g.N = N4; g.K = H; g.ldc = N4; g.B = B; g.T = T;
                         g.win_t0 = d == 0 ? sb : T - sb - sc; g.win_tc = sc; g.win_tiles = w.tiles;
@@ -660,8 +678,8 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         GemmArgs g{};
         g.A = cur; g.lda = curw; g.a_mode = 0; g.W = c->lin_w[j]; g.ldw = gemm_padded_k(curw); g.bias = c->lin_b[j]; g.C = Z[j & 1];
         g.M = (int)w.M; g.N = m.lin_hidden; g.K = curw; g.ldc = m.lin_hidden; g.B = B; g.T = T;
-        g.act = 1; g.leaky_slope = m.leaky_slope; g.Wsplit = c->lin_w_split[j];
-        HIPCHK(c, c->gemm_mode == 1 ? launch_gemm_split(g, s) : launch_gemm(g, s));
+        g.act = 1; g.leaky_slope = m.leaky_slope; g.Wsplit = c->lin_w_split[j]; g.Wsplit16 = c->lin_w_split16[j];
+        HIPCHK(c, run_gemm(g, s));
         cur = Z[j & 1];
         curw = m.lin_hidden;
     }
@@ -843,7 +861,7 @@ int uvad_label_runs(uvad_ctx *c, const uint8_t *d_labels, int B, int T, int max_
 
 int uvad_set_gemm_mode(uvad_ctx *c, int mode) {
     if (!c) return UVAD_E_ARG;
-    if (mode != 0 && mode != 1) return fail(c, UVAD_E_ARG, "gemm mode must be 0 (exact f32 MFMA) or 1 (split-bf16 x6)");
+    if (mode < 0 || mode > 2) return fail(c, UVAD_E_ARG, "gemm mode must be 0 (exact f32 MFMA), 1 (split-bf16 x6) or 2 (split-f16 x3)");
     c->gemm_mode = mode;
     return UVAD_OK;
 }

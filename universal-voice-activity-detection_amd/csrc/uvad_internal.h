@@ -19,6 +19,7 @@ struct GemmArgs {
                          // each row zero-padded to ldw = gemm_padded_k(K) floats
     int ldw;
     const unsigned short *Wsplit;   // gemm_split.hip only: the same matrix as three bf16 planes [3][N][ldw]
+    const unsigned short *Wsplit16; // gemm_f16x3.hip only: the same matrix as two f16 planes [2][N][ldw] (low plane x 2^11)
     const float *bias;   // [N] or nullptr
     float *C;
     int M, N, K;
@@ -41,6 +42,9 @@ int gemm_padded_k(int K);   // K rounded up to the kernel's K-step
 // ---- gemm_split.hip: same contract on the bf16 matrix cores with 3-way split operands ("bf16x6") --
 hipError_t launch_gemm_split(const GemmArgs &a, hipStream_t s);
 void split_weights_bf16x3(const float *w, size_t n, unsigned short *out /*[3][n]*/);
+// ---- gemm_f16x3.hip: same contract on the f16 matrix cores with 2-way split operands ("f16x3": half the MFMAs of bf16x6) --
+hipError_t launch_gemm_f16x3(const GemmArgs &a, hipStream_t s);
+bool split_weights_f16x2(const float *w, size_t n, unsigned short *out /*[2][n]*/);   // false: a weight is outside the f16 range
 
 // ---- lstm.hip -----------------------------------------------------------------------------
 // One layer, all directions: grid (tiles, dirs).  G holds x_t*W_ih^T + b_ih + b_hh with column

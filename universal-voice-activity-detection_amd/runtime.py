@@ -257,8 +257,9 @@ class VadRuntime:
             return out[:, :k]
 
     def set_gemm_mode(self, mode: str):
-        """"f32": exact f32 MFMA; "bf16x6": split-bf16 on the bf16 matrix cores (default)."""
-        self._check(self.lib.uvad_set_gemm_mode(self.ctx, {"f32": 0, "bf16x6": 1}[mode]))
+        """"f32": exact f32 MFMA; "bf16x6": 3-way split on the bf16 matrix cores; "f16x3": 2-way split on the f16 matrix
+        cores (default)."""
+        self._check(self.lib.uvad_set_gemm_mode(self.ctx, {"f32": 0, "bf16x6": 1, "f16x3": 2}[mode]))
 
     def der_counts(self, pred: "torch.Tensor", gt: "torch.Tensor") -> "torch.Tensor":
         """pred, gt (B, T) uint8 0/1 on the GPU -> (B, 2) int32 counts {false alarm, missed detection}."""
