@@ -181,12 +181,12 @@ def main():
     # per MI355X_MICROARCH.md + WRITE_SIZE); bench.py cannot collect PMC counters itself, so the committed
     # profile is quoted (null if absent or if the batch differs from the profiled one).
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_v2_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01_v4_hbm_traffic.json")
     if os.path.exists(tpath) and B == B_PER_GPU:
         kk = json.load(open(tpath))["kernels"]
-        key = "lstm_rec_kernel" if kern.startswith("lstm") else next((k for k in kk if k.startswith("gemm") and "4096000" in k), None)
+        key = next((k for k in kk if k.startswith("lstm_rec_kernel" if kern.startswith("lstm") else "gemm_f16x3_kernel grid=4096000")), None)
         if key in kk:
-            traffic, traffic_src = kk[key]["hbm_MB_per_launch"] * 1e6, "profiles/r01_v2_hbm_traffic.json"
+            traffic, traffic_src = kk[key]["hbm_MB_per_launch"] * 1e6, "profiles/r01_v4_hbm_traffic.json"
     roofline = {"kernel": kern, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                 "traffic_source": traffic_src, "avg_launch_ms": dur_ms, "flops_per_launch": flops_launch}

@@ -22,6 +22,11 @@ namespace uvad {
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDH = 40;   // LDH: LDS row stride in f16 elements
+#ifdef UVAD_G16_ABL_NOSTORE   // diagnostic build (tools/gemm_f16x3_ablate.hip): interior tiles skip their stores
+#define UVAD_G16_ABL_NOSTORE_COND full
+#else
+#define UVAD_G16_ABL_NOSTORE_COND false
+#endif
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
@@ -225,7 +230,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs a, int mt, 
             v[r] = __builtin_fmaf(LO[r], 0.00048828125f, ACC[r]) + bias;                                                                   \
             if (a.act == 1) v[r] = v[r] >= 0.f ? v[r] : a.leaky_slope * v[r];                        \
         }                                                                                            \
-        if (full) {                                                                                  \
+        if (UVAD_G16_ABL_NOSTORE_COND) {                                                             \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(v[r]));             \
+        } else if (full) {                                                                           \
             _Pragma("unroll") for (int r = 0; r < 16; ++r)                                           \
                 crow[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldc] = v[r];                               \
         } else {                                                                                     \
