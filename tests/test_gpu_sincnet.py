@@ -158,3 +158,42 @@ def test_pyannet_matches_reference_class_golden(name):
     print(f"{name}: SincNet feature err {ferr:.2e}, probability err {perr:.2e} vs the reference classes")
     assert feats.shape == g["sincnet_out"].shape and ferr < FEAT_TOL
     assert perr < LOGIT_TOL
+
+
+def test_main_with_sincnet_feature_extractor(monkeypatch):
+    """main.main(load_config()) with feature_extractor = "sincnet" (the reference's config switch, config/config.py:16-35):
+    model_name becomes PyanNet, encoding_dim 60, frame_shift 0.02; the predict script feeds raw audio to the model.
+    Probabilities are checked against the torch-CPU restatement of the same seeded network."""
+    import main as entry
+    from config.config import load_config
+    from uvad_amd.synth import synth_pcm
+    import uvad_amd
+    from oracle import torch_ref as tr
+    monkeypatch.setenv("UVAD_FEATURE_EXTRACTOR", "sincnet")
+    cfg = load_config()
+    assert cfg.model_name == "PyanNet" and cfg.model_dict.encoding_dim == 60 and cfg.frame_shift == 0.02
+    cfg.input.seconds = 5.0
+    cfg.input.num_utterances = 2
+    res = entry.main(cfg)
+    assert len(res) == 2 and res[0]["num_frames"] == 293
+    # the same network on the CPU: default-initialised SincNet front end (as uvad_amd.PyanNet builds it), seeded classifier
+    pcm = torch.from_numpy(synth_pcm(2, 80000, seed=cfg.input.seed))
+    ref_m = uvad_amd.PyanNet()
+    ref_m.build()
+    front = tr.TorchSincNet().eval()
+    fsd = ref_m.state_dict()
+    front.load_state_dict({"wav_norm1d.weight": fsd["sincnet.wav_norm1d.weight"], "wav_norm1d.bias": fsd["sincnet.wav_norm1d.bias"],
+                           "low_hz_": fsd["sincnet.conv1d.0.filterbank.low_hz_"], "band_hz_": fsd["sincnet.conv1d.0.filterbank.band_hz_"],
+                           **{f"norm1d.{i}.{p}": fsd[f"sincnet.norm1d.{i}.{p}"] for i in range(3) for p in ("weight", "bias")}}, strict=False)
+    # conv weights are torch-default random: take the ones the script's model actually used via the seed
+    torch.manual_seed(cfg.seed)
+    used = uvad_amd.VadModel(model_name="PyanNet", model_dict=dict(cfg.model_dict))
+    for i in range(2):
+        for p in ("weight", "bias"):
+            getattr(front.conv1d[i], p).data.copy_(getattr(used.model.sincnet.conv1d[i + 1], p).data)
+    cls = tr.TorchPyanNet2(60)
+    cls.load_state_dict(tr.seeded_state_dict(60, seed=cfg.weights_seed, scale=cfg.weights_scale))
+    _, probs = cls(front(pcm.unsqueeze(1)).transpose(1, 2).contiguous())
+    got = np.stack([r["probs"] for r in sorted(res, key=lambda r: r["recording_id"])])
+    print("sincnet main(): max prob err", np.abs(got - probs.numpy()).max())
+    assert np.abs(got - probs.numpy()).max() < 1e-3

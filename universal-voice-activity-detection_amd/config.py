@@ -28,7 +28,8 @@ def load_config() -> ConfigDict:
     cfg.num_devices = 1
     cfg.distributed_training = False
 
-    cfg.feature_extractor = "fbank"   # the log-mel path; sincnet / wav2vec2 / hubert are out of scope
+    cfg.feature_extractor = os.environ.get("UVAD_FEATURE_EXTRACTOR", "fbank")   # "fbank" (log-mel + PyanNet2) | "sincnet" (PyanNet);
+                                                                                # wav2vec2 / hubert are out of scope
     cfg.frame_shift = 0.01 if cfg.feature_extractor == "fbank" else 0.02
 
     cfg.supported_models = ["PyanNet", "PyanNet2"]

@@ -40,8 +40,10 @@ def _resolve_device(name: str) -> torch.device:
 def predict_vad(**kwargs):
     assert kwargs["model_name"] in kwargs["supported_models"], \
         f"Invalid model {kwargs['model_name']}. Model should be one of {kwargs['supported_models']}"
-    if kwargs["feature_extractor"] != "fbank":
-        raise NotImplementedError("only feature_extractor='fbank' (the log-mel path) is implemented")
+    if kwargs["feature_extractor"] not in ("fbank", "sincnet"):
+        raise NotImplementedError("feature_extractor must be 'fbank' (log-mel + PyanNet2) or 'sincnet' (waveform PyanNet); "
+                                  "the wav2vec2 / hubert encoders are outside the accelerated path")
+    sincnet = kwargs["feature_extractor"] == "sincnet"   # the reference's custom_vad path: the model consumes raw audio
     torch.manual_seed(kwargs["seed"])
     np.random.seed(kwargs["seed"])
     device = _resolve_device(kwargs["device"])
@@ -56,9 +58,11 @@ def predict_vad(**kwargs):
         seed_weights(model.model, kwargs.get("weights_seed", 1234), kwargs.get("weights_scale", 4.0))
     model = model.to(device).eval()
 
-    fb_cfg = FbankConfig(sampling_rate=16000, num_filters=model.model.encoding_dim,
-                         window_type=kwargs.get("window_type", "povey"), frame_shift=frame_shift, device="cuda")
-    extractor = Fbank(fb_cfg)
+    extractor = None
+    if not sincnet:
+        fb_cfg = FbankConfig(sampling_rate=16000, num_filters=model.model.encoding_dim,
+                             window_type=kwargs.get("window_type", "povey"), frame_shift=frame_shift, device="cuda")
+        extractor = Fbank(fb_cfg)
 
     src = kwargs["input"]
     recs: List[dict] = []
@@ -84,10 +88,14 @@ def predict_vad(**kwargs):
             group.append(order[i + len(group)])
         i += len(group)
         batch_pcm = torch.from_numpy(np.stack([recs[j]["pcm"] for j in group])).to(device)
-        feats = torch.stack(extractor.extract_batch(list(batch_pcm), sampling_rate=16000))
-        batch = {"inputs": feats, "input_lens": torch.full((len(group),), feats.shape[1]), "cut": [recs[j]["id"] for j in group]}
+        if sincnet:   # (batch, samples); VadModel._common_step adds the channel axis (vad_engine.py:252-255)
+            feats = batch_pcm
+            probs = model(feats.unsqueeze(1)).squeeze(-1)
+        else:
+            feats = torch.stack(extractor.extract_batch(list(batch_pcm), sampling_rate=16000))
+            probs = model(feats).squeeze(-1)
+        batch = {"inputs": feats, "input_lens": torch.full((len(group),), probs.shape[1]), "cut": [recs[j]["id"] for j in group]}
         labels = model.predict_step(batch, 0).squeeze(-1)          # (B, T) 0/1
-        probs = model(feats).squeeze(-1)
         intervals = labels_to_intervals_batch(labels, frame_shift)   # run-length walk on the GPU (uvad_label_runs)
         labels_h, probs_h = labels.cpu().numpy(), probs.cpu().numpy()
         for r, j in enumerate(group):
