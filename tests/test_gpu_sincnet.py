@@ -92,6 +92,16 @@ def test_sincnet_batch_invariance_and_determinism():
     assert torch.equal(full[17:18], single)
 
 
+def test_abi_frame_count_matches_reference_geometry():
+    import json, os
+    _, _, m = _pair()
+    rt = m.runtime(torch.device("cuda:0"))
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sincnet_geometry.json")))
+    for s, n in g["num_frames"].items():
+        assert rt.sincnet_num_frames(int(s)) == n, s
+    assert rt.sincnet_num_frames(990) == 0
+
+
 def test_sincnet_errors_are_loud():
     import uvad_amd
     from uvad_amd._lib import UvadError

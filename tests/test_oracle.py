@@ -159,3 +159,16 @@ def test_sincnet_restatement_matches_reference_class_golden(name):
     cls.load_state_dict(csd)
     _, probs = cls(feats.transpose(1, 2).contiguous())
     assert np.abs(probs.numpy() - g["probs"]).max() < 1e-5
+
+
+def test_sincnet_frame_count_matches_reference_receptive_field_module():
+    """tests/golden/sincnet_geometry.json holds get_num_frames / receptive_field_size of the reference's own
+    src/utils/receptive_field.py (tools/gen_golden_sincnet.py): 991 samples -> 1 frame, 1261 -> 2, 80000 -> 293."""
+    import json, os
+    import uvad_amd
+    from oracle import torch_ref as tr
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sincnet_geometry.json")))
+    for s, n in g["num_frames"].items():
+        assert tr.sincnet_num_frames(int(s)) == n, s
+        assert uvad_amd.SincNet.num_frames(int(s), 10) == n, s
+    assert g["receptive_field_size"]["1"] == 991 and g["receptive_field_size"]["2"] - g["receptive_field_size"]["1"] == 270

@@ -105,3 +105,22 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def geometry_fixture():
+    """tests/golden/sincnet_geometry.json: frame counts and receptive-field numbers from the reference's own
+    src/utils/receptive_field.py (pure Python, imported standalone from /root/reference)."""
+    import importlib.util, json
+    spec = importlib.util.spec_from_file_location("ref_receptive_field", os.path.join(REF, "src", "utils", "receptive_field.py"))
+    rf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rf)
+    samples = [991, 1000, 1260, 1261, 1300, 4000, 16000, 24000, 32037, 48000, 80000, 160000, 480000]
+    out = {"num_frames": {str(s): rf.get_num_frames(s) for s in samples},
+           "receptive_field_size": {str(n): rf.receptive_field_size(num_frames=n) for n in (1, 2, 293)}}
+    with open(os.path.join(REPO, "tests", "golden", "sincnet_geometry.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("sincnet_geometry.json:", out["num_frames"]["80000"], out["receptive_field_size"])
+
+
+if __name__ == "__main__":
+    geometry_fixture()
