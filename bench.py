@@ -80,47 +80,23 @@ def main():
     seed_weights(model, 1234, 4.0)
     model.attach_fbank(uvad_amd.FbankConfig(num_filters=N_MELS, window_type="hamming"))
     model = model.to(dev).eval()
-    rt = model.runtime(dev)
+    # Two steps in flight (uvad_amd.ForwardPipeline): the K steps are submitted alternately to two contexts (own weights
+    # copy, workspace and HIP stream each).  Every step is one complete uvad_forward over the batch; only the submission
+    # order of INDEPENDENT steps changes: while one step sits in its latency-bound recurrence (128 of the 256 CUs at
+    # B=256) the other step's feature kernel and projections run on the idle CUs.  --in-flight 1 = strictly sequential.
+    n_fly = max(1, min(args.in_flight, 4))
+    pipe = uvad_amd.ForwardPipeline(model, dev, depth=n_fly)
+    rts = pipe.runtimes
+    rt = rts[0]
     pcm = synth_pcm_device(B, S, seed=42, device=dev, first=rank * B)   # disjoint utterance ids per rank
     T = rt.num_frames(S)
 
-    # Two steps in flight: the K steps are submitted alternately to two contexts (own weights copy, workspace and HIP
-    # stream each).  Every step is one complete uvad_forward over the batch; only the submission order of INDEPENDENT
-    # steps changes: while one step sits in its latency-bound recurrence (128 of the 256 CUs at B=256) the other
-    # step's feature kernel and projections run on the idle CUs.  --in-flight 1 gives the strictly sequential loop.
-    from uvad_amd.runtime import VadRuntime
-    n_fly = max(1, min(args.in_flight, 4))
-    rts = [rt]
-    for _ in range(n_fly - 1):
-        r2 = VadRuntime(device=dev, fbank=model._fbank_cfg,
-                        model={"encoding_dim": model.encoding_dim, "lstm": model.hparams.lstm, "linear": model.hparams.linear})
-        r2.load_state_dict(model.state_dict())
-        rts.append(r2)
-    # HIP streams share a small pool of hardware queues and two streams on one queue serialise (which pairs collide
-    # depends on creation order: tools/overlap_probe.py), so the pair used is picked by a short untimed calibration.
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_fly)]
-    if n_fly >= 2:
-        cand = streams + [torch.cuda.Stream(device=dev) for _ in range(4)]
-        best = None
-        for first in range(len(cand) - n_fly + 1):
-            sel = list(range(first, first + n_fly))
-            for rep in range(2):   # first pass warms the selection up
-                torch.cuda.synchronize(dev)
-                t0 = time.perf_counter()
-                for k in range(2 * n_fly):
-                    with torch.cuda.stream(cand[sel[k % n_fly]]):
-                        rts[k % n_fly].forward(pcm, want_probs=False)
-                torch.cuda.synchronize(dev)
-                dt = (time.perf_counter() - t0) / (2 * n_fly)
-            if best is None or dt < best[0]:
-                best = (dt, sel)
-        streams = [cand[i] for i in best[1]]
-        log(f"streams {best[1]} of the candidates: {best[0] * 1e3:.2f} ms per step in calibration")
+    pipe._calibrate(pcm)   # picks HIP streams that really overlap (streams sharing a hardware queue serialise)
+    if pipe.calibration_ms is not None:
+        log(f"stream calibration: {pipe.calibration_ms:.2f} ms per step with {n_fly} in flight")
 
     def submit(k):
-        i = k % n_fly
-        with torch.cuda.stream(streams[i]):
-            return rts[i].forward(pcm, want_probs=False)
+        return pipe.submit(pcm)
 
     log(f"rank {rank}/{world}: inputs ready (B={B}, T={T}); warmup")
     for k in range(args.warmup):
@@ -137,10 +113,10 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         if k >= n_fly and live_events:   # stage times of the step this context ran last (waits for THAT step only; the other is in flight)
-            for name, v in rts[k % n_fly].timing_ms().items():
+            for name, v in rts[pipe.slot_of_next_submit()].timing_ms().items():
                 acc[name] += v
             n_acc += 1
-        logits, _ = submit(k)
+        pending = submit(k)
     torch.cuda.synchronize(dev)
     udist.barrier()
     elapsed = time.perf_counter() - t0

@@ -474,3 +474,29 @@ def test_tile16_throughput_kernel_matches_tile4():
     d = np.abs(outs[0] - outs[1]).max()
     print(f"tile16 vs tile4: max diff {d:.2e}")
     assert d < LOGIT_TOL
+
+
+def test_forward_pipeline_results_equal_sequential_path():
+    """uvad_amd.ForwardPipeline (several uvad_forward calls in flight on calibrated HIP streams): every batch's logits are
+    bit-identical to the ones the plain sequential path produces, whatever slot ran them."""
+    import uvad_amd
+    from uvad_amd.synth import seed_weights, synth_pcm_device
+    dev = torch.device("cuda:0")
+    m = uvad_amd.PyanNet2(encoding_dim=64)
+    m.build()
+    seed_weights(m, 1234, 4.0)
+    m.attach_fbank(uvad_amd.FbankConfig(num_filters=64, window_type="hamming"))
+    m = m.to(dev).eval()
+    batches = [synth_pcm_device(24, 48000, 70 + i, dev) for i in range(5)]
+    want = [m.forward_waveform(b)[0].clone() for b in batches]
+    pipe = uvad_amd.ForwardPipeline(m, dev, depth=2)
+    pend = [pipe.submit(b) for b in batches]
+    got = [p.result()[0] for p in pend]
+    assert pipe.streams is not None and len(pipe.streams) == 2 and pipe.streams[0] != pipe.streams[1]
+    for w, g in zip(want, got):
+        assert torch.equal(w, g)
+    pipe.close()
+    with pytest.raises(RuntimeError, match="attach_fbank"):
+        m2 = uvad_amd.PyanNet2(encoding_dim=64)
+        m2.build()
+        uvad_amd.ForwardPipeline(m2, dev)

@@ -7,10 +7,11 @@ from .features import Fbank, FbankConfig, make_mel_matrix, make_window
 from .models import PyanNet, PyanNet2
 from .postprocess import (detection_error, intervals_to_labels, labels_to_intervals, labels_to_intervals_batch, median_filter, median_window,
                           merge_intervals_with_buffer, split_into_windows)
+from .pipeline import ForwardPipeline
 from .runtime import VadRuntime
 from .scripts import predict_vad
 from .sincnet import SincNet
 
 __all__ = ["ConfigDict", "load_config", "VadModel", "Fbank", "FbankConfig", "make_mel_matrix", "make_window",
-           "PyanNet", "PyanNet2", "SincNet", "VadRuntime", "labels_to_intervals", "labels_to_intervals_batch", "median_filter", "median_window", "predict_vad",
+           "PyanNet", "PyanNet2", "SincNet", "VadRuntime", "ForwardPipeline", "labels_to_intervals", "labels_to_intervals_batch", "median_filter", "median_window", "predict_vad",
            "detection_error", "intervals_to_labels", "merge_intervals_with_buffer", "split_into_windows"]

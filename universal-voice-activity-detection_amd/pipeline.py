@@ -1,0 +1,98 @@
+"""ForwardPipeline: keep several uvad_forward calls in flight.
+
+Why: at the reference's batch sizes the recurrent kernel is a latency-bound chain that occupies only B/4 x directions
+of the 256 CUs (128 at B = 256); a second, independent batch submitted on another HIP stream runs its feature kernel and
+projections on the idle CUs (bench.py: 32 -> 44 M frames/s at BASELINE cfg 2).  Each slot is a full VadRuntime
+(own weights copy and workspace) bound to its own stream; results are identical to the sequential path (same kernels,
+same launch shapes).
+
+Stream choice: HIP maps streams onto a small pool of hardware queues and two streams that land on one queue serialise
+(tools/overlap_probe.py), so the slots' streams are picked by a short calibration on the first batch."""
+import time
+from typing import List, Optional
+
+import torch
+
+from .runtime import VadRuntime
+
+
+class Pending:
+    """Result of ForwardPipeline.submit: tensors that are complete once ``result()`` (or ``wait()``) returns."""
+
+    def __init__(self, event, logits, probs):
+        self._event, self._logits, self._probs = event, logits, probs
+
+    def wait(self):
+        self._event.synchronize()
+
+    def result(self):
+        self._event.synchronize()
+        return self._logits, self._probs
+
+
+class ForwardPipeline:
+    def __init__(self, model, device, depth: int = 2):
+        """model: a built uvad_amd.PyanNet2 with attach_fbank(...) done (weights are copied into every slot)."""
+        if getattr(model, "_fbank_cfg", None) is None:
+            raise RuntimeError("attach_fbank(FbankConfig(...)) first: the pipeline runs the fused PCM -> logits path")
+        self.device = torch.device(device)
+        self.depth = max(1, int(depth))
+        cfg = {"encoding_dim": model.encoding_dim, "lstm": model.hparams.lstm, "linear": model.hparams.linear}
+        self.runtimes: List[VadRuntime] = []
+        for _ in range(self.depth):
+            r = VadRuntime(device=self.device, fbank=model._fbank_cfg, model=cfg)
+            r.load_state_dict(model.state_dict())
+            self.runtimes.append(r)
+        self.streams: Optional[List[torch.cuda.Stream]] = None
+        self._k = 0
+        self.calibration_ms: Optional[float] = None
+
+    # ------------------------------------------------------------------ streams
+    def _calibrate(self, pcm):
+        n = self.depth
+        cand = [torch.cuda.Stream(device=self.device) for _ in range(n + 4)]
+        if n == 1:
+            self.streams = cand[:1]
+            return
+        best = None
+        for first in range(len(cand) - n + 1):
+            sel = cand[first:first + n]
+            for _ in range(2):   # the first pass warms the selection up
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                for k in range(2 * n):
+                    with torch.cuda.stream(sel[k % n]):
+                        self.runtimes[k % n].forward(pcm, want_probs=False)
+                torch.cuda.synchronize(self.device)
+                dt = (time.perf_counter() - t0) / (2 * n)
+            if best is None or dt < best[0]:
+                best = (dt, sel)
+        self.calibration_ms, self.streams = best[0] * 1e3, best[1]
+
+    # ------------------------------------------------------------------ use
+    def submit(self, pcm: torch.Tensor, want_logits: bool = True, want_probs: bool = False) -> Pending:
+        """pcm (B, S) f32 on the device, ready on the CURRENT stream.  Returns at once; the step runs on the next slot's stream."""
+        if self.streams is None:
+            self._calibrate(pcm)
+        i = self._k % self.depth
+        self._k += 1
+        s = self.streams[i]
+        s.wait_stream(torch.cuda.current_stream(self.device))   # the input was produced on the caller's stream
+        with torch.cuda.stream(s):
+            logits, probs = self.runtimes[i].forward(pcm, want_logits=want_logits, want_probs=want_probs)
+            ev = torch.cuda.Event()
+            ev.record(s)
+        pcm.record_stream(s)
+        return Pending(ev, logits, probs)
+
+    def slot_of_next_submit(self) -> int:
+        return self._k % self.depth
+
+    def synchronize(self):
+        for s in self.streams or []:
+            s.synchronize()
+
+    def close(self):
+        for r in self.runtimes:
+            r.close()
+        self.runtimes = []
