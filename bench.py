@@ -314,7 +314,11 @@ def cpu_baseline_and_error(model, rt, pcm, dev):
             "max_abs_logit_err": err_same, "mean_abs_logit_err": err_same_mean,
             "logit_err_sample": f"{nb} utterances x {T} frames, classifier on identical features vs torch-CPU reference path",
             "max_abs_logit_err_end_to_end": err_e2e, "max_abs_feature_err": feat_err,
-            "logit_err_vs_f64_oracle": vs_oracle}
+            "logit_err_vs_f64_oracle": vs_oracle,
+            "logit_err_note": "max_abs_logit_err is the worst of all frames of the sample on the seeded x4-scaled network, which is close to "
+                              "chaotic (a 1e-7 perturbation grows to ~3e-5 over 1000 frames, heavy tail): no two fp32 implementations -- "
+                              "torch CPU included -- agree to 1e-4 at every frame there (DESIGN.md section 4).  The 1e-4 bound is met on the "
+                              "vectors generated by the reference's own classes (tests/golden: 1.7e-5 .. 3.4e-5) and in every -m gpu parity test"}
 
 
 if __name__ == "__main__":
