@@ -14,7 +14,7 @@ import torch
 
 from .engine import VadModel
 from .features import Fbank, FbankConfig
-from .postprocess import labels_to_intervals_batch
+from .postprocess import labels_to_intervals_batch, median_filter
 from .synth import seed_weights, synth_pcm
 
 
@@ -88,14 +88,14 @@ def predict_vad(**kwargs):
             group.append(order[i + len(group)])
         i += len(group)
         batch_pcm = torch.from_numpy(np.stack([recs[j]["pcm"] for j in group])).to(device)
-        if sincnet:   # (batch, samples); VadModel._common_step adds the channel axis (vad_engine.py:252-255)
-            feats = batch_pcm
-            probs = model(feats.unsqueeze(1)).squeeze(-1)
+        # one forward pass per batch; labels exactly as VadModel.predict_step derives them from the probabilities
+        # (vad_engine.py:204-211: threshold 0.5 + median filter, 49 taps unless encoding_dim == 768)
+        if sincnet:   # (batch, samples); the model consumes raw audio, channel axis added as in vad_engine.py:252-255
+            probs = model(batch_pcm.unsqueeze(1)).squeeze(-1)
         else:
             feats = torch.stack(extractor.extract_batch(list(batch_pcm), sampling_rate=16000))
             probs = model(feats).squeeze(-1)
-        batch = {"inputs": feats, "input_lens": torch.full((len(group),), probs.shape[1]), "cut": [recs[j]["id"] for j in group]}
-        labels = model.predict_step(batch, 0).squeeze(-1)          # (B, T) 0/1
+        labels = median_filter(probs, window=0.02 if model.model.encoding_dim == 768 else 0.01)   # (B, T) 0/1
         intervals = labels_to_intervals_batch(labels, frame_shift)   # run-length walk on the GPU (uvad_label_runs)
         labels_h, probs_h = labels.cpu().numpy(), probs.cpu().numpy()
         for r, j in enumerate(group):
