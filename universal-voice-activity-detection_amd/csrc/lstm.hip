@@ -25,7 +25,10 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int PD = 4;  // gate prefetch depth (steps)
+#ifndef UVAD_LSTM_PD
+#define UVAD_LSTM_PD 4   // 8 fits (252 of 256 registers) but measured the same on one box: 6.11 vs 6.11 ms per step, 1.36 vs 1.36 ms per launch
+#endif
+constexpr int PD = 4;  // gate prefetch depth (steps) of the variant kernels; the main kernel uses UVAD_LSTM_PD (below)
 
 __device__ __forceinline__ float sigmoid_f(float x) {
     // 1/(1+2^(-x*log2e)); v_exp_f32 + v_rcp_f32 (1 ulp each).  |x| <= 16 => abs err < 3e-7.
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
     constexpr int UW = H / WAVES;   // hidden units per wave
     constexpr int RB = UW / 16;     // 16-unit MFMA row blocks per wave
     constexpr int HS = H + 4;   // LDS row stride (floats): the 4 sequence rows land on disjoint banks
+    constexpr int PD = HAS_G2 ? 4 : UVAD_LSTM_PD;   // gate prefetch depth (steps)
     static_assert(RB >= 1 && UW % 16 == 0 && UW * WAVES == H, "H must split into 16-unit blocks over the waves");
 
     __shared__ __attribute__((aligned(16))) float hbuf[2][SEQ_TILE][HS];
