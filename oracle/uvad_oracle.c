@@ -228,8 +228,11 @@ void orc_classify(const orc_model_cfg *m, const float *weights, const float *fea
                   float *lstm_out, float *lin_out, float *logits, float *probs) {
     int D = m->bidirectional ? 2 : 1, H = m->hidden, W = H * D;
     size_t rows = (size_t)B * T;
-    float *cur = (float *)malloc(sizeof(float) * rows * (size_t)(m->in_dim > W ? m->in_dim : W));
-    float *nxt = (float *)malloc(sizeof(float) * rows * (size_t)W);
+    /* both ping-pong buffers hold the widest activation of the network (features, LSTM output, feed-forward) */
+    size_t wide = (size_t)(m->in_dim > W ? m->in_dim : W);
+    if (m->lin_layers > 0 && (size_t)m->lin_hidden > wide) wide = (size_t)m->lin_hidden;
+    float *cur = (float *)malloc(sizeof(float) * rows * wide);
+    float *nxt = (float *)malloc(sizeof(float) * rows * wide);
     memcpy(cur, feats, sizeof(float) * rows * m->in_dim);
     const float *p = weights;
     int in = m->in_dim;
@@ -242,9 +245,6 @@ void orc_classify(const orc_model_cfg *m, const float *weights, const float *fea
             orc_lstm_layer(cur, B, T, in, H, d, w_ih, w_hh, b_ih, b_hh, nxt, W, d * H, 0, 0, 0, 0);
         }
         float *tmp = cur; cur = nxt; nxt = tmp;
-        if (k == 0 && m->in_dim > W) { /* cur was sized for max(in_dim, W); keep both big enough */
-            nxt = (float *)realloc(nxt, sizeof(float) * rows * (size_t)(m->in_dim > W ? m->in_dim : W));
-        }
         in = W;
     }
     if (lstm_out) memcpy(lstm_out, cur, sizeof(float) * rows * W);

@@ -500,3 +500,40 @@ def test_forward_pipeline_results_equal_sequential_path():
         m2 = uvad_amd.PyanNet2(encoding_dim=64)
         m2.build()
         uvad_amd.ForwardPipeline(m2, dev)
+
+
+def test_random_shape_sweep_vs_oracle():
+    """Seeded sweep over the constructor space and ragged shapes (batch not a multiple of the 4-sequence tile, frame counts
+    around the 4 / 16 / 32 / 128 tile edges, widths that are only multiples of 4, 0..3 feed-forward layers, both hidden
+    sizes, both directions) against the C oracle, in all three GEMM modes for the first cases."""
+    import uvad_amd
+    from uvad_amd.synth import seed_weights
+    from oracle import c_oracle as co
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for case in range(24):
+        H = int(rng.choice([64, 128]))
+        L = int(rng.integers(1, 5))
+        bi = bool(rng.integers(0, 2))
+        F = int(rng.choice([4, 12, 40, 60, 64, 80, 100, 132]))
+        lin_l = int(rng.integers(0, 4))
+        lin_h = int(rng.choice([4, 32, 100, 128]))
+        B = int(rng.choice([1, 2, 3, 5, 7, 8, 13, 33]))
+        T = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 33, 63, 127, 129, 200]))
+        m = uvad_amd.PyanNet2(lstm={"hidden_size": H, "num_layers": L, "bidirectional": bi},
+                              linear={"hidden_size": lin_h, "num_layers": lin_l}, encoding_dim=F)
+        m.build()
+        seed_weights(m, 100 + case, 2.0)
+        m = m.to(dev).eval()
+        g = torch.Generator().manual_seed(case)
+        feats = torch.randn(B, T, F, generator=g) * 2.0 - 3.0
+        sd = {k: v.cpu().numpy() for k, v in m.state_dict().items()}
+        want, _ = co.classify(sd, co.ModelCfg(F, H, L, int(bi), lin_h, lin_l, 0.01), feats.numpy())
+        for mode in (("f16x3", "bf16x6", "f32") if case < 8 else ("f16x3",)):
+            m.runtime(dev).set_gemm_mode(mode)
+            logits, _ = m.forward_logits(feats.to(dev))
+            err = float(np.abs(logits.cpu().numpy() - want).max())
+            worst = max(worst, err)
+            assert err < LOGIT_TOL, (case, mode, dict(H=H, L=L, bi=bi, F=F, lin_l=lin_l, lin_h=lin_h, B=B, T=T), err)
+    print(f"shape sweep: worst logit err {worst:.2e}")

@@ -172,3 +172,18 @@ def test_sincnet_frame_count_matches_reference_receptive_field_module():
         assert tr.sincnet_num_frames(int(s)) == n, s
         assert uvad_amd.SincNet.num_frames(int(s), 10) == n, s
     assert g["receptive_field_size"]["1"] == 991 and g["receptive_field_size"]["2"] - g["receptive_field_size"]["1"] == 270
+
+
+def test_c_oracle_handles_wide_feed_forward_and_input():
+    """Regression: the C oracle's scratch buffers must hold the widest activation (lin_hidden > hidden*dirs once
+    corrupted the heap).  Cross-checked against the torch restatement on awkward constructor shapes."""
+    from oracle import c_oracle as co, torch_ref as tr
+    for (F, H, L, bi, lin_h, lin_l, B, T) in ((60, 64, 3, False, 100, 2, 8, 2), (132, 64, 2, False, 128, 0, 2, 1),
+                                              (4, 64, 1, False, 200, 3, 3, 5), (300, 128, 1, True, 4, 1, 2, 3)):
+        sd = tr.seeded_state_dict(F, H, L, bi, lin_h, lin_l, seed=9, scale=2.0)
+        g = torch.Generator().manual_seed(1)
+        feats = torch.randn(B, T, F, generator=g)
+        want, _ = co.classify({k: v.numpy() for k, v in sd.items()}, co.ModelCfg(F, H, L, int(bi), lin_h, lin_l, 0.01), feats.numpy())
+        ref = tr.TorchPyanNet2(F, H, L, bi, lin_h, lin_l)
+        ref.load_state_dict(sd)
+        assert np.abs(ref(feats)[0].numpy() - want).max() < 1e-5
