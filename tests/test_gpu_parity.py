@@ -537,3 +537,77 @@ def test_random_shape_sweep_vs_oracle():
             worst = max(worst, err)
             assert err < LOGIT_TOL, (case, mode, dict(H=H, L=L, bi=bi, F=F, lin_l=lin_l, lin_h=lin_h, B=B, T=T), err)
     print(f"shape sweep: worst logit err {worst:.2e}")
+
+
+def test_fbank_random_config_sweep_vs_oracle():
+    """Seeded sweep over the FbankConfig space the kernel implements (frame length / hop, filters, window, pre-emphasis,
+    DC removal, snip_edges, low / high cut-offs) and ragged lengths, float and int16 PCM, against the float64-DFT C oracle."""
+    import uvad_amd
+    from oracle import c_oracle as co, torch_ref as tr
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    for case in range(20):
+        flen = float(rng.choice([0.025, 0.02, 0.032, 0.03]))
+        fshift = float(rng.choice([0.01, 0.005, 0.016]))
+        F = int(rng.choice([8, 23, 40, 64, 80, 128]))
+        window = str(rng.choice(["povey", "hamming", "hanning", "rectangular"]))
+        pre = float(rng.choice([0.97, 0.0, 0.5]))
+        dc = bool(rng.integers(0, 2))
+        snip = bool(rng.integers(0, 2))
+        low, high = float(rng.choice([20.0, 0.0, 100.0])), float(rng.choice([-400.0, 0.0, 6000.0]))
+        B = int(rng.integers(1, 5))
+        L, sh = int(round(flen * 16000)), int(round(fshift * 16000))
+        S = int(rng.integers(max(L, 600), 40000))
+        cfg = uvad_amd.FbankConfig(frame_length=flen, frame_shift=fshift, num_filters=F, window_type=window, preemph_coeff=pre,
+                                   remove_dc_offset=dc, snip_edges=snip, low_freq=low, high_freq=high)
+        oc = co.default_fbank_cfg(F, frame_len=L, frame_shift=sh, preemph=pre, remove_dc=int(dc), snip_edges=int(snip), low_hz=low, high_hz=high)
+        pcm = tr.synth_pcm(B, S, seed=900 + case)
+        want = co.fbank(pcm, oc, co.window(window, L), co.mel_banks(oc))
+        rt = uvad_amd.Fbank(cfg)._runtime(dev)
+        got = rt.fbank(torch.from_numpy(pcm).to(dev)).cpu().numpy()
+        assert got.shape == want.shape, (case, got.shape, want.shape)
+        err = float(np.abs(got - want).max()) if want.size else 0.0
+        worst = max(worst, err)
+        assert err < FEAT_TOL, (case, dict(flen=flen, fshift=fshift, F=F, window=window, pre=pre, dc=dc, snip=snip, low=low, high=high, B=B, S=S), err)
+        if case % 4 == 0:   # int16 ingest of the same signal
+            q = np.round(pcm * 32767.0).astype(np.int16)
+            want16 = co.fbank(q.astype(np.float32) / 32768.0, oc, co.window(window, L), co.mel_banks(oc))
+            got16 = rt.fbank(torch.from_numpy(q).to(dev)).cpu().numpy()
+            assert np.abs(got16 - want16).max() < FEAT_TOL, case
+    print(f"fbank sweep: worst log-mel err {worst:.2e}")
+
+
+def test_streaming_random_chunk_sweep_equals_offline():
+    """Lock-step streams with awkward chunk sizes (smaller than a hop, not a multiple of the hop, larger than a second),
+    stream counts off the 4-sequence tile, 1- and 2-layer causal models at both hidden sizes: every emitted frame equals
+    the offline logits of the whole signal and the number of emitted frames is exactly the frames whose last sample arrived."""
+    import uvad_amd
+    from uvad_amd.synth import synth_pcm, seed_weights
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(31)
+    for case in range(8):
+        chunk = int(rng.choice([80, 200, 333, 480, 1024, 4800, 20000]))
+        B = int(rng.choice([1, 3, 5, 8]))
+        H = int(rng.choice([64, 128]))
+        L = int(rng.integers(1, 3))
+        F = int(rng.choice([40, 64, 80]))
+        steps = max(3, int(40000 // chunk))
+        S = steps * chunk
+        pcm = synth_pcm(B, S, seed=400 + case)
+        m = uvad_amd.PyanNet2(lstm={"bidirectional": False, "hidden_size": H, "num_layers": L}, encoding_dim=F)
+        m.build()
+        seed_weights(m, 50 + case, 3.0)
+        m.attach_fbank(uvad_amd.FbankConfig(num_filters=F))
+        m = m.to(dev).eval()
+        rt = m.runtime(dev)
+        x = torch.from_numpy(pcm).to(dev)
+        offline, _ = rt.forward(x)
+        st = rt.stream_open(B, chunk)
+        outs = [rt.stream_step(st, x[:, i * chunk:(i + 1) * chunk].contiguous()).clone() for i in range(steps)]
+        got = torch.cat(outs, dim=1)
+        n = got.shape[1]
+        assert n == max(0, (S + 120 - 400) // 160 + 1), (case, chunk, n)
+        err = float((got - offline[:, :n]).abs().max())
+        print(f"stream sweep case {case}: chunk {chunk} B {B} H {H} L {L} F {F}: {n} frames, max diff {err:.2e}")
+        assert err < LOGIT_TOL, (case, chunk, B, H, L, F, err)

@@ -207,3 +207,24 @@ def test_main_with_sincnet_feature_extractor(monkeypatch):
     got = np.stack([r["probs"] for r in sorted(res, key=lambda r: r["recording_id"])])
     print("sincnet main(): max prob err", np.abs(got - probs.numpy()).max())
     assert np.abs(got - probs.numpy()).max() < 1e-3
+
+
+def test_sincnet_random_length_sweep_vs_oracle():
+    """Ragged waveform lengths around the tile edges of the three stages (85 / 42 / 42 pooled outputs per tile) and
+    batch sizes around the persistent-grid boundaries, against the torch-CPU restatement."""
+    from oracle import torch_ref as tr
+    front, _, m = _pair(seed=123)
+    rt = m.runtime(torch.device("cuda:0"))
+    rng = np.random.default_rng(8)
+    lengths = [1261, 2791, 2800, 2801, 7921, 12345, 25751, 25761, 39999, 64000]
+    worst = 0.0
+    for S in lengths:
+        B = int(rng.integers(1, 7))
+        wav = torch.from_numpy(tr.synth_pcm(B, S, seed=int(rng.integers(0, 10000))))
+        want = front(wav.unsqueeze(1)).transpose(1, 2).numpy()
+        got = rt.sincnet(wav.cuda()).cpu().numpy()
+        assert got.shape == want.shape, (S, got.shape, want.shape)
+        err = float(np.abs(got - want).max())
+        worst = max(worst, err)
+        assert err < (FEAT_TOL if want.shape[1] > 2 else 5e-4), (S, B, err)   # 2-frame outputs: the instance norm divides by ~sqrt(eps)
+    print(f"SincNet length sweep: worst feature err {worst:.2e}")
