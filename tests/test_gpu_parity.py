@@ -611,3 +611,26 @@ def test_streaming_random_chunk_sweep_equals_offline():
         err = float((got - offline[:, :n]).abs().max())
         print(f"stream sweep case {case}: chunk {chunk} B {B} H {H} L {L} F {F}: {n} frames, max diff {err:.2e}")
         assert err < LOGIT_TOL, (case, chunk, B, H, L, F, err)
+
+
+def test_fbank_full_size_properties_shift_and_gain():
+    """Size-independent properties of the feature stage at the full BASELINE cfg-2 size (256 x 10 s, 64 filters):
+    (i) dropping the first hop of samples shifts the interior frames by exactly one frame;
+    (ii) doubling the signal adds log(4) to every log-mel value (power spectrum x 4), away from the log floor."""
+    import uvad_amd
+    from uvad_amd.synth import synth_pcm_device
+    dev = torch.device("cuda:0")
+    rt = uvad_amd.Fbank(uvad_amd.FbankConfig(num_filters=64, window_type="hamming"))._runtime(dev)
+    pcm = synth_pcm_device(256, 160000, 7, dev) * 0.5
+    f0 = rt.fbank(pcm)
+    f1 = rt.fbank(pcm[:, 160:].contiguous())
+    assert f0.shape == (256, 1000, 64) and f1.shape == (256, 999, 64)
+    shift_err = float((f1[:, 2:-2] - f0[:, 3:-2]).abs().max())      # interior frames only (edges are reflect-padded)
+    f2 = rt.fbank(pcm * 2.0)
+    gain_err = float((f2 - f0 - float(np.log(4.0))).abs().max())
+    print(f"fbank full size: shift err {shift_err:.2e}, gain err {gain_err:.2e}")
+    # a frame shares its complex FFT with a different neighbour after the shift: fp32 rounding differs, and the weakest of
+    # the 16 M log-mel values amplifies that most (same bound as the oracle comparison); the gain property is exact
+    # up to the rounding of log().
+    assert shift_err < FEAT_TOL and gain_err < 1e-5
+    assert torch.isfinite(f0).all()
