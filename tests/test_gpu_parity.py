@@ -215,7 +215,6 @@ def test_main_config1_plumbing_30s():
 
 
 def test_library_is_loaded_and_errors_are_loud():
-    import ctypes as C
     import uvad_amd
     from uvad_amd import _lib
     lib = _lib.load()

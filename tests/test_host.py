@@ -1,5 +1,4 @@
 """CPU tests of the host-side mirror of the reference interface (no compute calls)."""
-import os
 
 import numpy as np
 import pytest

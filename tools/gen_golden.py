@@ -25,7 +25,6 @@ and the medfilt'ed labels of predict_step (scipy.signal.medfilt, kernel 49) as "
 import os
 import sys
 import tempfile
-import types
 
 import numpy as np
 import torch

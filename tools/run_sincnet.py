@@ -3,7 +3,7 @@
 src/datasets/custom_vad.py:47): times uvad_sincnet alone and the whole uvad_forward_wav, and checks a slice of the
 batch against the torch-CPU restatement.  FLOP accounting of the front end (multiply-add = 2 FLOP), per utterance:
   conv1 7975 x 80 x 251, conv2 2654 x 60 x 400, conv3 880 x 60 x 300  ->  0.479 GFLOP / 5 s cut."""
-import argparse, json, os, sys, time
+import argparse, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import uvad_amd

@@ -9,7 +9,7 @@ runs in the fused HIP kernel behind ``uvad_fbank`` (csrc/fbank.hip).  The window
 matrix are built here on the host (float64 numpy) and uploaded once with ``uvad_set_tables``.
 """
 from dataclasses import dataclass, asdict
-from typing import List, Optional, Sequence, Union
+from typing import List, Optional
 
 import numpy as np
 
