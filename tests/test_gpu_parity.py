@@ -633,3 +633,33 @@ def test_fbank_full_size_properties_shift_and_gain():
     # up to the rounding of log().
     assert shift_err < FEAT_TOL and gain_err < 1e-5
     assert torch.isfinite(f0).all()
+
+
+def test_long_utterance_ten_minutes():
+    """One 10-minute recording in a single call (T = 60 000 frames, 240 000 sequential recurrent steps): frame count,
+    finiteness and logits against the torch-CPU reference path on identical features (weights x2: a contractive
+    network, so the comparison measures the kernels and not chaotic error growth)."""
+    import uvad_amd
+    from uvad_amd.synth import seed_weights, synth_pcm_device
+    from oracle import torch_ref as tr
+    dev = torch.device("cuda:0")
+    m = uvad_amd.PyanNet2(encoding_dim=64)
+    m.build()
+    seed_weights(m, 1234, 2.0)
+    m.attach_fbank(uvad_amd.FbankConfig(num_filters=64, window_type="hamming"))
+    m = m.to(dev).eval()
+    rt = m.runtime(dev)
+    pcm = synth_pcm_device(1, 16000 * 600, 3, dev)
+    feats = rt.fbank(pcm)
+    logits, probs = rt.classify(feats)
+    torch.cuda.synchronize()
+    assert logits.shape == (1, 60000) and torch.isfinite(logits).all()
+    cpu = tr.TorchPyanNet2(64)
+    cpu.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    want = cpu(feats.cpu())[0]
+    err = float((logits.cpu() - want).abs().max())
+    print(f"10-minute utterance: max |GPU - CPU| logit err {err:.2e} (logit range {want.min():.3f}..{want.max():.3f})")
+    assert err < LOGIT_TOL
+    fused, _ = rt.forward(pcm)
+    assert torch.equal(fused, logits)       # uvad_forward == uvad_fbank + uvad_classify
