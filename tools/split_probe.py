@@ -22,4 +22,19 @@ for parts in (1, 2, 4):
         [p.wait() for p in pend]
     dt = (time.perf_counter() - t0) / 10
     print(f"one 256 x 10 s batch as {parts} concurrent part(s): {dt*1e3:.2f} ms per batch = {256000/dt/1e6:.1f} M frames/s", flush=True)
+    if parts == 2:   # the same two halves with the second one submitted a little later (host spin), so that they run out of phase
+        for delay_us in (150, 300, 600, 1000):
+            def run():
+                a = pipe.submit(chunks[0])
+                t = time.perf_counter()
+                while (time.perf_counter() - t) * 1e6 < delay_us:
+                    pass
+                b = pipe.submit(chunks[1])
+                a.wait(); b.wait()
+            run(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                run()
+            dt = (time.perf_counter() - t0) / 10
+            print(f"   two halves, second submitted {delay_us} us later: {dt*1e3:.2f} ms per batch", flush=True)
     pipe.close()
