@@ -121,6 +121,10 @@ def test_reference_import_paths_resolve():
     from src.scripts import predict_vad
     assert A is B is uvad_amd.PyanNet2 and VadModel is uvad_amd.VadModel
     assert callable(median_filter) and callable(predict_vad)
+    from src.models import PyanNet as C
+    from src.models.segmentation.PyanNet import PyanNet as D
+    from src.models.blocks.sincnet import SincNet
+    assert C is D is uvad_amd.PyanNet and SincNet is uvad_amd.SincNet
 
 
 def test_fbank_config_defaults_are_lhotse_defaults():
