@@ -1,4 +1,5 @@
 """CPU tests of the host-side mirror of the reference interface (no compute calls)."""
+import os
 
 import numpy as np
 import pytest
@@ -169,3 +170,25 @@ def test_interval_scoring_helpers_follow_the_reference():
     lab = uvad_amd.intervals_to_labels([(0.02, 0.05), (0.08, 0.2)], 0.1, 0.01)
     assert lab.tolist() == [0, 0, 1, 1, 1, 0, 0, 0, 1, 1]
     assert len(uvad_amd.intervals_to_labels([], 1.005, 0.01)) == 101
+
+
+def test_bench_line_contract_on_the_committed_sample():
+    """The bench contract (driver side): one JSON object with the required keys, the metric / unit of BASELINE.json, a roofline
+    and a cpu_baseline object.  Checked on the line committed under profiles/ (bench.py itself needs a GPU)."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = sorted(glob.glob(os.path.join(root, "profiles", "r01_v*_bench.json")))[-1]
+    o = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in o, k
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert o["unit"] == "frames/s" and "frames/sec" in o["metric"] and "frames/sec" in base["metric"]
+    assert o["higher_is_better"] is True and o["scaling"] == "weak" and o["vs_baseline"] is None and o["data"] == "synthetic"
+    assert "workload" in o["config"] and not any(k in o["config"] for k in ("model", "seq_len", "global_batch"))
+    r = o["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] in ("GB/s", "TFLOP/s")
+    c = o["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s"
+    assert abs(o["value"] - o["config"]["utterances_per_gpu"] * o["config"]["frames_per_utterance"] * o["n_gpus"] / (o["ms_per_step"] * 1e-3)) / o["value"] < 1e-6
