@@ -84,7 +84,7 @@ def main():
     # copy, workspace and HIP stream each).  Every step is one complete uvad_forward over the batch; only the submission
     # order of INDEPENDENT steps changes: while one step sits in its latency-bound recurrence (128 of the 256 CUs at
     # B=256) the other step's feature kernel and projections run on the idle CUs.  --in-flight 1 = strictly sequential.
-    n_fly = max(1, min(args.in_flight, 4))
+    n_fly = max(1, min(args.in_flight, 8))
     pipe = uvad_amd.ForwardPipeline(model, dev, depth=n_fly)
     rts = pipe.runtimes
     rt = rts[0]
