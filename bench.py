@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* peak
+PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak (the pipe the split-f16 GEMM runs on)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 B_PER_GPU, SECONDS, N_MELS = 256, 10.0, 64
 
@@ -91,9 +92,7 @@ def main():
     pcm = synth_pcm_device(B, S, seed=42, device=dev, first=rank * B)   # disjoint utterance ids per rank
     T = rt.num_frames(S)
 
-    pipe._calibrate(pcm)   # picks HIP streams that really overlap (streams sharing a hardware queue serialise)
-    if pipe.calibration_ms is not None:
-        log(f"stream calibration: {pipe.calibration_ms:.2f} ms per step with {n_fly} in flight")
+    log(f"{n_fly} pairwise-concurrent HIP stream(s) selected by uvad_streams_overlap after {pipe.streams_tried} tries")
 
     def submit(k):
         return pipe.submit(pcm)
@@ -144,27 +143,39 @@ def main():
         "head": {"ms": ms["head"], "bound": "mfma", "achieved_TFLOPs": frames_step * head_f / (ms["head"] * 1e-3) / 1e12},
     }
     stage["fbank"]["frac"] = stage["fbank"]["achieved_GBs"] / PEAK_HBM_GBS if stage["fbank"]["achieved_GBs"] else None
-    for k in ("proj", "recurrent", "head"):
-        stage[k]["frac"] = stage[k]["achieved_TFLOPs"] / PEAK_F32_MFMA_TFLOPS
+    # The recurrence runs exact-f32 MFMAs: its fraction is against the f32-MFMA peak.  The projections and the feed-forward
+    # layers run gemm_f16x3_kernel: THREE f16 MFMA products per f32-equivalent product on the 2.5 PFLOP/s f16 pipe, so the
+    # honest pipe fraction is 3 x the f32-equivalent rate over the f16 peak; the f32-equivalent rate is kept as information only
+    # (it is NOT a fraction of the f32 peak: no f32 MFMA is issued).
+    stage["recurrent"]["frac"] = stage["recurrent"]["achieved_TFLOPs"] / PEAK_F32_MFMA_TFLOPS
+    stage["recurrent"]["peak"] = "f32 MFMA 157.3 TFLOP/s"
+    for k in ("proj", "head"):
+        stage[k]["kernel"] = "gemm_f16x3_kernel" + (" + classifier_kernel" if k == "head" else "")
+        stage[k]["f32_equivalent_TFLOPs"] = stage[k].pop("achieved_TFLOPs")
+        stage[k]["f16_pipe_TFLOPs"] = 3.0 * stage[k]["f32_equivalent_TFLOPs"]
+        stage[k]["frac"] = stage[k]["f16_pipe_TFLOPs"] / PEAK_F16_MFMA_TFLOPS
+        stage[k]["peak"] = "f16 MFMA 2500 TFLOP/s (3 MFMA products per f32-equivalent product)"
     # dominant kernel: the recurrent kernel (one launch per layer) or the projection GEMM (one per layer)
     L = 4
     if ms["recurrent"] >= ms["proj"]:
-        kern, flops_launch, dur_ms = "lstm_rec_kernel<128>", frames_step * rec_f / L, ms["recurrent"] / L
+        kern, flops_launch, dur_ms, peak = "lstm_rec_kernel<128, 8>", frames_step * rec_f / L, ms["recurrent"] / L, PEAK_F32_MFMA_TFLOPS
     else:
-        kern, flops_launch, dur_ms = "gemm_f32_kernel", frames_step * proj_f / L, ms["proj"] / L
+        kern, flops_launch, dur_ms, peak = "gemm_f16x3_kernel", 3.0 * frames_step * proj_f / L, ms["proj"] / L, PEAK_F16_MFMA_TFLOPS
     achieved = flops_launch / (dur_ms * 1e-3) / 1e12
     # HBM bytes per launch of that kernel from the rocprofv3 PMC passes of this same workload (FETCH_SIZE doubled
     # per MI355X_MICROARCH.md + WRITE_SIZE); bench.py cannot collect PMC counters itself, so the committed
     # profile is quoted (null if absent or if the batch differs from the profiled one).
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_v4_hbm_traffic.json")
-    if os.path.exists(tpath) and B == B_PER_GPU:
-        kk = json.load(open(tpath))["kernels"]
-        key = next((k for k in kk if k.startswith("lstm_rec_kernel" if kern.startswith("lstm") else "gemm_f16x3_kernel grid=4096000")), None)
-        if key in kk:
-            traffic, traffic_src = kk[key]["hbm_MB_per_launch"] * 1e6, "profiles/r01_v4_hbm_traffic.json"
-    roofline = {"kernel": kern, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+    for name in ("r02_hbm_traffic.json", "r01_v4_hbm_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tpath) and B == B_PER_GPU:
+            kk = json.load(open(tpath))["kernels"]
+            key = next((k for k in kk if k.startswith("lstm_rec_kernel" if kern.startswith("lstm") else "gemm_f16x3_kernel grid=4096000")), None)
+            if key in kk:
+                traffic, traffic_src = kk[key]["hbm_MB_per_launch"] * 1e6, "profiles/" + name
+                break
+    roofline = {"kernel": kern, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch",
                 "traffic_source": traffic_src, "avg_launch_ms": dur_ms, "flops_per_launch": flops_launch}
     if n_fly > 1:
         roofline["note"] = ("launch duration measured while the other in-flight step's kernels share the GPU (this kernel owns 128 of the "
@@ -179,7 +190,7 @@ def main():
                                "PyanNet2 4xBiLSTM(128)+2xFC classifier (BASELINE configs[1])",
                    "utterances_per_gpu": B, "frames_per_utterance": T, "n_mels": N_MELS, "sharding": f"utterance-shard x{world}"},
         "roofline": roofline, "stages": stage,
-        "classifier_frac_of_f32_mfma_peak": frames_step * (proj_f + rec_f + head_f) / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+        "classifier_f32_equivalent_TFLOPs": frames_step * (proj_f + rec_f + head_f) / (elapsed / args.steps) / 1e12,
     }
     out["config"]["steps_in_flight"] = n_fly
     out["stages_note"] = ("per-stage HIP-event times of one step, measured inside the timed region on that step's own stream; with 2 steps "
@@ -221,7 +232,7 @@ def sequential_latency(rt, dev, pcm, steps, world):
     launch_ms = rec / 3 / 4
     tf = pcm.shape[0] * rt.num_frames(pcm.shape[1]) * rec_f / 4 / (launch_ms * 1e-3) / 1e12
     return {"value": frames / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps_in_flight": 1,
-            "roofline": {"kernel": "lstm_rec_kernel<128>", "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"kernel": "lstm_rec_kernel<128, 8>", "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": launch_ms},
             "note": "same step, one at a time on one stream; not the headline value"}
 
@@ -263,9 +274,10 @@ def sincnet_throughput(dev, B=256, S=80000, reps=5):
 
 
 def cpu_baseline_and_error(model, rt, pcm, dev):
-    """Reference CPU path (oracle/torch_ref: the reference's operator sequence on torch CPU ops) on a
-    bounded sample of the SAME utterances and weights, all host cores; plus logit error GPU vs CPU."""
-    from oracle import torch_ref as tr
+    """Reference CPU path (oracle/torch_ref: the reference's operator sequence on torch CPU ops) on a bounded sample of the
+    SAME utterances and weights, all host cores given to the job, 1 warm-up + 3 timed reps; plus the logit error of the GPU
+    path and of that CPU path against the float64 evaluation of the network on identical features."""
+    from oracle import torch_ref as tr, parity_stats as ps
     # the GPU box gives one job a share of the host (16 cores per GPU), not the whole machine:
     # os.cpu_count() reports every core and over-subscribing them makes the torch CPU path crawl.
     cores = int(os.environ.get("UVAD_CPU_THREADS", min(os.cpu_count() or 1, 16)))
@@ -281,44 +293,50 @@ def cpu_baseline_and_error(model, rt, pcm, dev):
         return cpu(feats)[0]
 
     x_all = pcm.cpu()
-    run(x_all[:4])                                  # warm-up
+    run(x_all[:16])                                 # warm-up
     t = time.perf_counter(); run(x_all[:16]); dt16 = time.perf_counter() - t
     log(f"cpu_baseline: 16 utterances took {dt16:.2f} s")
-    nb = int(max(16, min(x_all.shape[0], 16 * 15.0 / max(dt16, 1e-3))))   # ~15 s of CPU work
-    t = time.perf_counter(); ref = run(x_all[:nb]); dt = time.perf_counter() - t
+    nb = int(max(16, min(x_all.shape[0], 16 * 6.0 / max(dt16, 1e-3))))   # ~6 s per rep, 3 reps
+    reps = []
+    for _ in range(3):
+        t = time.perf_counter(); ref = run(x_all[:nb]); reps.append(time.perf_counter() - t)
+    dt = sorted(reps)[1]                             # median of 3
     T = ref.shape[1]
     # (1) the BASELINE bound: classifier on IDENTICAL inputs.  The reference's model boundary is the
     #     feature tensor (PyanNet2.forward(audio_feats); features are precomputed offline there), so the
     #     GPU features are handed to both paths.
     feats_gpu = rt.fbank(pcm[:nb].contiguous())
     gl_same, _ = rt.classify(feats_gpu, want_probs=False)
-    ref_same = cpu(feats_gpu.cpu())[0]
-    err_same = float((gl_same.cpu() - ref_same).abs().max())
-    err_same_mean = float((gl_same.cpu() - ref_same).abs().mean())
-    # (2) end to end from PCM: adds the fp32-FFT difference between the two feature stages (~3e-5 in the
-    #     log-mel domain), which the x4-scaled, near-chaotic test network amplifies ~200x.
+    gl_same = gl_same.cpu().numpy()
+    ref_same = cpu(feats_gpu.cpu())[0].numpy()
+    vs_cpu = ps.error_stats(gl_same, ref_same)
+    # (2) both against the float64 truth (float64 throughout, torch CPU ops; pinned to oracle/uvad_oracle.c: orc_classify_f64)
+    #     on the first 64 utterances: the x4-scaled test network is near-chaotic, so what matters is that the GPU path is as
+    #     close to the truth as the reference's fp32 CPU path is.
+    ns = min(64, nb)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    truth = ps.truth_logits(sd, feats_gpu[:ns].cpu(), F, threads=cores)
+    st_gpu, st_cpu = ps.error_stats(gl_same[:ns], truth), ps.error_stats(ref_same[:ns], truth)
+    # (3) end to end from PCM: adds the fp32-FFT difference between the two feature stages (~1e-4 in the
+    #     log-mel domain), which the x4-scaled network amplifies.
     gl, _ = rt.forward(pcm[:nb].contiguous(), want_probs=False)
     err_e2e = float((gl.cpu() - ref).abs().max())
     feat_err = float((feats_gpu.cpu() - tr.torch_fbank(x_all[:nb], win, mel)).abs().max())
-    # (3) both fp32 paths against the double-accumulating C oracle on 4 utterances: how far apart two
-    #     correct fp32 implementations are allowed to be on this (x4-scaled, near-chaotic) network
-    from oracle import c_oracle as co
-    ns = min(4, nb)
-    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    orc, _ = co.classify(sd, co.ModelCfg(F, 128, 4, 1, 128, 2, 0.01), feats_gpu[:ns].cpu().numpy())
-    vs_oracle = {"gpu": float(abs(gl_same[:ns].cpu().numpy() - orc).max()), "cpu_fp32": float(abs(ref_same[:ns].numpy() - orc).max()),
-                 "sample": f"{ns} utterances x {T} frames, identical features, oracle = oracle/uvad_oracle.c (double accumulation)"}
     return {"cpu_baseline": {"value": nb * T / dt, "unit": "frames/s", "cores": cores, "kind": "port",
                              "sample": f"first {nb} of the {x_all.shape[0]} utterances x 10 s, fbank + classifier, "
-                                       f"torch {torch.__version__} CPU ops, {cores} threads, 1 rep ({dt:.1f} s)"},
-            "max_abs_logit_err": err_same, "mean_abs_logit_err": err_same_mean,
+                                       f"torch {torch.__version__} CPU ops, {cores} threads, 1 warm-up + 3 reps "
+                                       f"({', '.join(f'{r:.1f}' for r in reps)} s; median used)"},
+            "max_abs_logit_err": vs_cpu["max"], "mean_abs_logit_err": vs_cpu["mean"], "frames_over_1e-4": vs_cpu["frames_over_bound"],
             "logit_err_sample": f"{nb} utterances x {T} frames, classifier on identical features vs torch-CPU reference path",
+            "logit_err_vs_cpu_fp32": vs_cpu,
+            "logit_err_vs_f64_truth": {"gpu": st_gpu, "cpu_fp32": st_cpu,
+                                       "sample": f"{ns} utterances x {T} frames, identical features, truth = float64 throughout"},
             "max_abs_logit_err_end_to_end": err_e2e, "max_abs_feature_err": feat_err,
-            "logit_err_vs_f64_oracle": vs_oracle,
-            "logit_err_note": "max_abs_logit_err is the worst of all frames of the sample on the seeded x4-scaled network, which is close to "
-                              "chaotic (a 1e-7 perturbation grows to ~3e-5 over 1000 frames, heavy tail): no two fp32 implementations -- "
-                              "torch CPU included -- agree to 1e-4 at every frame there (DESIGN.md section 4).  The 1e-4 bound is met on the "
-                              "vectors generated by the reference's own classes (tests/golden: 1.7e-5 .. 3.4e-5) and in every -m gpu parity test"}
+            "logit_err_note": "seeded weights are scaled x4 (SURVEY App. B) which makes the network near-chaotic: a 1e-7 perturbation grows "
+                              "to 1e-5..1e-3 at some frames, so two fp32 implementations -- torch CPU included -- differ by more than 1e-4 at "
+                              "a few of the 256 000 frames; logit_err_vs_f64_truth shows the GPU path is as close to the float64 truth as "
+                              "the fp32 CPU path is.  With weights x2 / x1 the GPU-vs-CPU max error over all frames is < 1e-4 "
+                              "(tests/test_gpu_scale.py::test_cfg2_full_size_logit_parity)"}
 
 
 if __name__ == "__main__":

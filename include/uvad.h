@@ -17,7 +17,9 @@
  *   - every pointer named d_* is a DEVICE pointer owned by the caller; the library never
  *     allocates or frees caller tensors.  It owns only the weights / tables inside uvad_ctx.
  *   - compute calls are ASYNCHRONOUS on `stream` (a hipStream_t passed as void*; NULL = the
- *     default stream) and perform no allocation or synchronisation => hipGraph-capturable.
+ *     default stream) and perform no allocation or synchronisation => hipGraph-capturable
+ *     (exception: uvad_stream_step, see there).  Every call makes the context's device current
+ *     (hipSetDevice) before it enqueues, so a multi-GPU process may interleave contexts freely.
  *   - one ctx per (device, model); a ctx is NOT thread-safe (the reference drives the model
  *     from a single thread: Trainer(devices=1), src/scripts/predict.py:79-85).
  *   - there is NO CPU fallback: on a machine without a gfx950 device uvad_create fails.
@@ -39,7 +41,7 @@ extern "C" {
 #define UVAD_E_WORKSPACE   -4
 #define UVAD_E_UNSUPPORTED -5
 
-#define UVAD_ABI_VERSION 1
+#define UVAD_ABI_VERSION 2
 
 typedef struct uvad_ctx uvad_ctx; /* opaque */
 
@@ -89,7 +91,9 @@ int uvad_set_tables(uvad_ctx *, const float *window, const float *mel);
  * (src/scripts/predict.py:77). */
 int uvad_set_weight(uvad_ctx *, const char *torch_key, const float *host, const int64_t *shape, int ndim /* 1..3 */);
 
-/* Checks that every tensor is present, repacks into kernel layouts and uploads. */
+/* Checks that every tensor is present, repacks into kernel layouts and uploads.  May be called again after
+ * further uvad_set_weight calls (weight hot-swap): it waits for the device to go idle, frees the previous
+ * upload and replaces it. */
 int uvad_finalize(uvad_ctx *);
 
 /* T for S samples (lhotse framing; data/test_data.py:23 pins T = S/160 for 5 s cuts). */
@@ -131,7 +135,10 @@ int uvad_get_taps(uvad_ctx *, int B, int T, float *d_lstm_out, float *d_lin_out,
  * 0..k-1); the return value is k >= 0 (same for every stream) or a negative error.  d_state is caller-owned
  * device memory of uvad_stream_state_bytes(ctx, B) bytes holding the PCM tail and (h, c) of every layer;
  * uvad_stream_reset (re)starts all B streams.  The right-edge reflection of the offline path needs the end
- * of the signal and is therefore never produced (streams are open-ended). */
+ * of the signal and is therefore never produced (streams are open-ended).
+ * uvad_stream_step is asynchronous but NOT replay-safe under hipGraph capture: the number of complete frames, the
+ * PCM-tail ping-pong parity and the first-chunk reflection are host-side counters baked into the launch arguments
+ * at enqueue time, so a captured step replayed twice would repeat one step.  Enqueue it per chunk. */
 size_t uvad_stream_state_bytes(const uvad_ctx *, int B);
 size_t uvad_stream_workspace_bytes(const uvad_ctx *, int B, int chunk);
 int uvad_stream_reset(uvad_ctx *, void *d_state, int B, void *stream);
@@ -199,15 +206,31 @@ int uvad_forward_wav(uvad_ctx *, const float *d_wav, int B, int64_t S, float *d_
 
 /* Which kernel runs the time-parallel contractions (input projections, feed-forward layers):
  *   0  exact f32: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain, bit-compatible with f32 FMA arithmetic;
- *   1  f32-accurate on the bf16 matrix cores: operands split exactly into three bf16 pieces, six
- *      v_mfma_f32_32x32x16_bf16 per product term set, f32 accumulation (dropped terms <= 2^-23 relative);
- *   2  (default) f32-accurate on the f16 matrix cores: operands split into two f16 pieces (the low one scaled by
+ *   1  (default) f32-accurate on the f16 matrix cores: operands split into two f16 pieces (the low one scaled by
  *      2^11), three v_mfma_f32_32x32x16_f16 per product term set in two f32 accumulator sets (dropped term
- *      <= 2^-22 relative, below the rounding noise of the f32 accumulation): half the matrix-core work of mode 1.
- *      Needs |weight| < 65504; a context whose weights do not fit runs mode 1 instead.
- * All three are held to the same 1e-4 logit bound by the tests.  The environment variable UVAD_GEMM = f32 | bf16x6 |
- * f16x3 selects the mode at uvad_create. */
+ *      <= 2^-22 relative, below the rounding noise of the f32 accumulation).
+ *      Needs operands inside the f16 range (|x| < 65504).  The library guarantees that without the caller's help:
+ *      weights (and the bound they put on the feed-forward activations) are checked by uvad_finalize and a context
+ *      that fails runs mode 0; features handed to uvad_classify are checked on the device and a batch that fails runs
+ *      its first projection in mode 0 (no host synchronisation: both kernels are enqueued, a device flag picks one).
+ * Both are held to the same 1e-4 logit bound by the tests.  Replaces nothing in the reference (torch picks its GEMM). */
 int uvad_set_gemm_mode(uvad_ctx *, int mode);
+
+/* How many sequences one recurrent workgroup owns (the time loop of nn.LSTM, PyanNet2.py:169-172):
+ *   4   latency form (v_mfma_f32_4x4x1): B/4 x directions workgroups, the right one up to a few hundred sequences;
+ *   16  throughput form (v_mfma_f32_16x16x4, hidden_size 128 only): fewer, heavier workgroups for B >= 1024;
+ *   0   (default) chosen per call from the batch size (16 when B/4 x directions >= 512).
+ * uvad_get_recurrent_tile returns what the most recent uvad_classify / uvad_forward* call launched (4 or 16; 0 before
+ * the first call).  Results agree to rounding between the two (tests/test_gpu_parity.py). */
+int uvad_set_recurrent_tile(uvad_ctx *, int sequences);
+int uvad_get_recurrent_tile(const uvad_ctx *);
+
+/* Do two HIP streams run concurrently?  HIP maps streams onto a small pool of hardware queues and two streams that share
+ * a queue serialise, which silently defeats "two batches in flight" (ForwardPipeline).  The probe enqueues a 3 ms
+ * spinning wave on stream_a and an empty kernel on stream_b and reports whether b's retired while a's was still running:
+ * 1 = concurrent, 0 = serialised, negative = error.  Synchronises both streams (call it at set-up time, not per batch).
+ * Replaces nothing in the reference (its inference is one batch at a time, src/scripts/predict.py:98). */
+int uvad_streams_overlap(uvad_ctx *, void *stream_a, void *stream_b);
 
 /* Per-stage device timing of the most recent uvad_forward/uvad_classify made with timing enabled
  * (uvad_set_timing(ctx, 1) inserts hipEvents on the caller's stream; not graph-capturable while

@@ -121,6 +121,18 @@ def classify(sd, mcfg, feats, taps=False):
     return logits, probs
 
 
+def classify_f64(sd, mcfg, feats):
+    """Float64-throughout evaluation of the same network on the f32 weights / features: logits (B, T) float64."""
+    feats = np.ascontiguousarray(feats, np.float32)
+    B, T, F = feats.shape
+    assert F == mcfg.in_dim
+    blob = flatten_state_dict(sd, mcfg)
+    logits = np.empty((B, T), np.float64)
+    lib().orc_classify_f64(C.byref(mcfg), _fp(blob), _fp(feats), C.c_int(B), C.c_int(T),
+                           logits.ctypes.data_as(C.POINTER(C.c_double)))
+    return logits
+
+
 def median_filter(probs, kernel):
     probs = np.ascontiguousarray(probs, np.float32)
     B, T = probs.shape

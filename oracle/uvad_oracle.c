@@ -281,6 +281,82 @@ void orc_classify(const orc_model_cfg *m, const float *weights, const float *fea
     free(cur); free(nxt);
 }
 
+/* ---------------------------------------------------------------- classifier, float64 throughout
+ * Same network (PyanNet2.py:154-187) with EVERY intermediate in double: gate pre-activations, (h, c), layer outputs,
+ * feed-forward activations.  Weights and features are the f32 values.  This is the "truth" the fp32 implementations
+ * (torch CPU, the HIP path, orc_classify above, whose state is f32) are measured against on the near-chaotic x4 test
+ * network, where the distance between two fp32 implementations says little. */
+static void lstm_layer_f64(const double *x, int T, int in, int H, int reverse, const float *w_ih, const float *w_hh,
+                           const float *b_ih, const float *b_hh, double *y, int ystride, int yoff) {
+    double *h = (double *)calloc((size_t)H, sizeof(double)), *c = (double *)calloc((size_t)H, sizeof(double));
+    double *g = (double *)malloc(sizeof(double) * 4 * (size_t)H);
+    for (int s = 0; s < T; ++s) {
+        int t = reverse ? T - 1 - s : s;
+        const double *xt = x + (size_t)t * in;
+        for (int r = 0; r < 4 * H; ++r) {
+            double acc = (double)b_ih[r] + (double)b_hh[r];
+            const float *wi = w_ih + (size_t)r * in, *wh = w_hh + (size_t)r * H;
+            for (int k = 0; k < in; ++k) acc += (double)wi[k] * xt[k];
+            for (int k = 0; k < H; ++k) acc += (double)wh[k] * h[k];
+            g[r] = acc;
+        }
+        double *yt = y + (size_t)t * ystride + yoff;
+        for (int u = 0; u < H; ++u) {
+            double ig = 1.0 / (1.0 + exp(-g[u])), fg = 1.0 / (1.0 + exp(-g[H + u]));
+            double gg = tanh(g[2 * H + u]), og = 1.0 / (1.0 + exp(-g[3 * H + u]));
+            c[u] = fg * c[u] + ig * gg;
+            h[u] = og * tanh(c[u]);
+            yt[u] = h[u];
+        }
+    }
+    free(h); free(c); free(g);
+}
+
+/* feats [B][T][F] f32 -> logits [B][T] double (same weight blob as orc_classify) */
+void orc_classify_f64(const orc_model_cfg *m, const float *weights, const float *feats, int B, int T, double *logits) {
+    int D = m->bidirectional ? 2 : 1, H = m->hidden, W = H * D;
+    size_t wide = (size_t)(m->in_dim > W ? m->in_dim : W);
+    if (m->lin_layers > 0 && (size_t)m->lin_hidden > wide) wide = (size_t)m->lin_hidden;
+    double *cur = (double *)malloc(sizeof(double) * (size_t)T * wide), *nxt = (double *)malloc(sizeof(double) * (size_t)T * wide);
+    for (int b = 0; b < B; ++b) {
+        for (size_t i = 0; i < (size_t)T * m->in_dim; ++i) cur[i] = feats[(size_t)b * T * m->in_dim + i];
+        const float *p = weights;
+        int in = m->in_dim;
+        for (int k = 0; k < m->num_layers; ++k) {
+            for (int d = 0; d < D; ++d) {
+                const float *w_ih = p; p += (size_t)4 * H * in;
+                const float *w_hh = p; p += (size_t)4 * H * H;
+                const float *b_ih = p; p += 4 * H;
+                const float *b_hh = p; p += 4 * H;
+                lstm_layer_f64(cur, T, in, H, d, w_ih, w_hh, b_ih, b_hh, nxt, W, d * H);
+            }
+            double *tmp = cur; cur = nxt; nxt = tmp;
+            in = W;
+        }
+        int prev = W;
+        for (int j = 0; j < m->lin_layers; ++j) {
+            int out = m->lin_hidden;
+            const float *w = p; p += (size_t)out * prev;
+            const float *bias = p; p += out;
+            for (int t = 0; t < T; ++t)
+                for (int o = 0; o < out; ++o) {
+                    double acc = bias[o];
+                    for (int k = 0; k < prev; ++k) acc += (double)w[(size_t)o * prev + k] * cur[(size_t)t * prev + k];
+                    nxt[(size_t)t * out + o] = acc >= 0.0 ? acc : (double)m->leaky_slope * acc;
+                }
+            double *tmp = cur; cur = nxt; nxt = tmp;
+            prev = out;
+        }
+        const float *wc = p; p += prev;
+        for (int t = 0; t < T; ++t) {
+            double acc = *p;
+            for (int k = 0; k < prev; ++k) acc += (double)wc[k] * cur[(size_t)t * prev + k];
+            logits[(size_t)b * T + t] = acc;
+        }
+    }
+    free(cur); free(nxt);
+}
+
 /* ------------------------------------------------------------ post-processing */
 
 /* helper.py:66-97: x>=0.5 -> 1 else 0, then odd-length median with zero-padded edges

@@ -291,7 +291,7 @@ def test_streaming_rejects_bidirectional_and_unreset_state():
     assert ei.value.code == -5
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x6", "f16x3"])
+@pytest.mark.parametrize("mode", ["f32", "f16x3"])
 @pytest.mark.parametrize("name", ["pyannet2_f64_T1000", "pyannet2_f80_T500", "pyannet2_f64_T3000"])
 def test_all_gemm_modes_meet_the_logit_bound(mode, name):
     g, sd, case = load_golden(name)
@@ -308,7 +308,9 @@ def test_all_gemm_modes_meet_the_logit_bound(mode, name):
 def test_f16x3_gemm_is_f32_accurate_and_handles_awkward_operands():
     """The 2-way f16 split against the exact f32-MFMA kernel on one projection-shaped product with operands spanning
     the magnitudes of the path (tiny activations, log-mel-sized features, weights x4): relative error of the same order
-    as f32 accumulation noise; a weight outside the f16 range makes the context fall back to the bf16 split."""
+    as f32 accumulation noise.  Operands OUTSIDE the f16 range never reach the split: a weight >= 65504 makes the context
+    run the exact kernel (host check in uvad_finalize), a feature >= 65504 or Inf handed to uvad_classify makes that
+    call's first projection run the exact kernel (device-side flag), with the answer of the exact mode in both cases."""
     import uvad_amd
     from oracle import torch_ref as tr
     dev = torch.device("cuda:0")
@@ -322,19 +324,71 @@ def test_f16x3_gemm_is_f32_accurate_and_handles_awkward_operands():
     feats[:, :, :8] *= 1e-4                 # tiny columns
     feats[:, :, 8:16] = feats[:, :, 8:16] * 3.0   # up to ~ +-40
     out = {}
-    for mode in ("f32", "f16x3", "bf16x6"):
+    for mode in ("f32", "f16x3"):
         m.runtime(dev).set_gemm_mode(mode)
         out[mode], _ = m.forward_logits(feats.to(dev))
     torch.cuda.synchronize()
     e16 = (out["f16x3"] - out["f32"]).abs().max().item()
-    ebf = (out["bf16x6"] - out["f32"]).abs().max().item()
-    print(f"single layer: f16x3 vs exact f32 MFMA {e16:.2e}, bf16x6 vs exact {ebf:.2e}")
-    assert e16 < 2e-5 and ebf < 2e-5
+    print(f"single layer: f16x3 vs exact f32 MFMA {e16:.2e}")
+    assert e16 < 2e-5
+    # (a) features outside the f16 range (the reference accepts any float; e.g. unnormalised 768-dim SSL features)
+    big = feats.clone()
+    big[1, 7, 3] = 1.0e5
+    big[5, 100, 60] = -7.0e4
+    for mode in ("f32", "f16x3"):
+        m.runtime(dev).set_gemm_mode(mode)
+        out[mode], _ = m.forward_logits(big.to(dev))
+    assert torch.isfinite(out["f16x3"]).all()
+    assert torch.equal(out["f16x3"], out["f32"])          # single layer, no feed-forward: the whole model ran the exact kernel
+    assert (out["f32"][1] - m.forward_logits(feats.to(dev))[0][1]).abs().max() > 1e-2     # the big value did matter
+    inf = feats.clone()
+    inf[2, 5, 0] = float("inf")
+    m.runtime(dev).set_gemm_mode("f16x3")
+    li, _ = m.forward_logits(inf.to(dev))
+    ref = tr.TorchPyanNet2(64, 128, 1, False, lin_layers=0)
+    ref.load_state_dict(sd)
+    want = ref(inf)[0]
+    assert torch.equal(torch.isfinite(li.cpu()), torch.isfinite(want))     # non-finite exactly where torch's are
+    ok = torch.isfinite(want)
+    assert (li.cpu()[ok] - want[ok]).abs().max() < LOGIT_TOL
+    # (b) a weight outside the f16 range: the context runs the exact kernel everywhere
     sd2 = {k: v.clone() for k, v in sd.items()}
-    sd2["lstm.weight_ih_l0"][0, 0] = 1.0e5     # outside the f16 range
+    sd2["lstm.weight_ih_l0"][0, 0] = 1.0e5
     m.load_state_dict(sd2)
-    big, _ = m.forward_logits(feats.to(dev))     # runs (bf16 split) and stays finite
-    assert torch.isfinite(big).all()
+    m.runtime(dev).set_gemm_mode("f16x3")
+    l16, _ = m.forward_logits(feats.to(dev))
+    m.runtime(dev).set_gemm_mode("f32")
+    l32, _ = m.forward_logits(feats.to(dev))
+    assert torch.isfinite(l16).all() and torch.equal(l16, l32)
+
+
+def test_finalize_twice_hot_swaps_weights():
+    """uvad_finalize is idempotent: loading a second state_dict into the same context (weight hot-swap through the C ABI)
+    replaces the device copy -- results follow the new weights, and the first set can be restored bit for bit."""
+    import uvad_amd
+    from oracle import torch_ref as tr
+    dev = torch.device("cuda:0")
+    sd_a = tr.seeded_state_dict(64, seed=11, scale=2.0)
+    sd_b = tr.seeded_state_dict(64, seed=12, scale=2.0)
+    m = uvad_amd.PyanNet2(encoding_dim=64)
+    m.build()
+    m.load_state_dict(sd_a)
+    m = m.to(dev).eval()
+    x = torch.randn(3, 50, 64, generator=torch.Generator().manual_seed(1)).to(dev) * 2 - 3
+    la = m.forward_logits(x)[0].clone()
+    rt = m.runtime(dev)
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    for _ in range(20):
+        rt.load_state_dict(sd_b)
+        lb = m.forward_logits(x)[0].clone()
+        rt.load_state_dict(sd_a)
+        la2 = m.forward_logits(x)[0].clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(la, lb) and torch.equal(la, la2)
+    cpu = tr.TorchPyanNet2(64); cpu.load_state_dict(sd_b)
+    assert (lb.cpu() - cpu(x.cpu())[0]).abs().max() < LOGIT_TOL
+    leaked = free0 - torch.cuda.mem_get_info(dev)[0]
+    assert leaked < 8 << 20, f"40 reloads leaked {leaked} bytes of device memory"
 
 
 def test_label_runs_on_device_equal_the_host_walk_and_the_oracle():
@@ -416,67 +470,36 @@ def test_model_variants_vs_oracle(cfg):
     assert np.abs(probs.cpu().numpy() - wantp).max() < LOGIT_TOL
 
 
-def test_overlapped_projection_path_matches_classic():
-    """UVAD_OVERLAP=1 path (chunked recurrence + side-stream K-split projections) == classic path to rounding."""
-    import subprocess, sys, os
-    code = (
-        "import os, sys, numpy as np, torch\n"
-        "sys.path.insert(0, os.getcwd())\n"
-        "import uvad_amd\n"
-        "from uvad_amd.synth import seed_weights\n"
-        "dev = torch.device('cuda:0')\n"
-        "m = uvad_amd.PyanNet2(encoding_dim=64); m.build(); seed_weights(m, 1234, 4.0); m = m.to(dev).eval()\n"
-        "g = torch.Generator().manual_seed(4321)\n"
-        "x = (torch.randn(6, 700, 64, generator=g) * 4 - 8).to(dev)\n"
-        "l, _ = m.forward_logits(x)\n"
-        "np.save(sys.argv[1], l.cpu().numpy())\n")
-    outs = []
-    for ov in ("0", "1"):
-        path = f"/tmp/uvad_ovl_{ov}.npy"
-        env = dict(os.environ, UVAD_OVERLAP=ov)
-        subprocess.check_call([sys.executable, "-c", code, path], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        outs.append(np.load(path))
-    d = np.abs(outs[0] - outs[1]).max()
-    print(f"overlap on vs off: max diff {d:.2e}")
-    assert d < LOGIT_TOL
-
-
 def test_tile16_throughput_kernel_matches_tile4():
-    """The 16-sequence recurrent kernel (auto-selected for >= 512 tile-directions; forced here with
-    UVAD_LSTM=tile16) against the 4-sequence kernel and the reference golden, incl. a partial last workgroup."""
-    import subprocess, sys, os
-    code = (
-        "import os, sys, numpy as np, torch\n"
-        "sys.path.insert(0, os.getcwd())\n"
-        "sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))\n"
-        "import uvad_amd\n"
-        "from conftest import load_golden\n"
-        "g, sd, case = load_golden('pyannet2_f64_T1000')\n"
-        "dev = torch.device('cuda:0')\n"
-        "m = uvad_amd.PyanNet2(encoding_dim=64); m.build(); m.load_state_dict(sd); m = m.to(dev).eval()\n"
-        "x = torch.from_numpy(g['feats']).to(dev)\n"
-        "gen = torch.Generator().manual_seed(1)\n"
-        "extra = (torch.randn(19, 1000, 64, generator=gen) * 4 - 8).to(dev)\n"     # 21 sequences: 6 tiles -> 2 workgroups of 16, second partial
-        "l, _ = m.forward_logits(torch.cat([x, extra]))\n"
-        "np.save(sys.argv[1], l.cpu().numpy())\n"
-        "print('golden err', float(np.abs(l[:2].cpu().numpy() - g['logits']).max()))\n")
-    outs = []
-    for mode in ("tile4", "tile16"):
-        path = f"/tmp/uvad_lstm_{mode}.npy"
-        env = dict(os.environ, UVAD_LSTM=mode)
-        out = subprocess.check_output([sys.executable, "-c", code, path], env=env, text=True,
-                                      cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        err = float(out.strip().split()[-1])
-        print(f"{mode}: logit err vs reference golden {err:.2e}")
+    """The 16-sequence recurrent kernel (chosen by itself from B >= 1024; forced here with uvad_set_recurrent_tile) against
+    the 4-sequence kernel and the reference golden, incl. a partial last workgroup (21 sequences = 6 tiles)."""
+    import uvad_amd
+    g, sd, case = load_golden("pyannet2_f64_T1000")
+    dev = torch.device("cuda:0")
+    m = _model(case, sd, dev)
+    rt = m.runtime(dev)
+    x = torch.from_numpy(g["feats"]).to(dev)
+    extra = (torch.randn(19, 1000, 64, generator=torch.Generator().manual_seed(1)) * 4 - 8).to(dev)
+    xs = torch.cat([x, extra])
+    outs = {}
+    for tile in (4, 16):
+        rt.set_recurrent_tile(tile)
+        l, _ = m.forward_logits(xs)
+        assert rt.recurrent_tile() == tile
+        err = float(np.abs(l[:2].cpu().numpy() - g["logits"]).max())
+        print(f"tile {tile}: logit err vs reference golden {err:.2e}")
         assert err < LOGIT_TOL
-        outs.append(np.load(path))
-    d = np.abs(outs[0] - outs[1]).max()
+        outs[tile] = l.clone()
+    rt.set_recurrent_tile(0)
+    l, _ = m.forward_logits(xs)
+    assert rt.recurrent_tile() == 4 and torch.equal(l, outs[4])     # 21 sequences: the latency form by default
+    d = float((outs[4] - outs[16]).abs().max())
     print(f"tile16 vs tile4: max diff {d:.2e}")
     assert d < LOGIT_TOL
 
 
 def test_forward_pipeline_results_equal_sequential_path():
-    """uvad_amd.ForwardPipeline (several uvad_forward calls in flight on calibrated HIP streams): every batch's logits are
+    """uvad_amd.ForwardPipeline (several uvad_forward calls in flight on HIP streams proven concurrent by uvad_streams_overlap): every batch's logits are
     bit-identical to the ones the plain sequential path produces, whatever slot ran them."""
     import uvad_amd
     from uvad_amd.synth import seed_weights, synth_pcm_device
@@ -529,7 +552,7 @@ def test_random_shape_sweep_vs_oracle():
         feats = torch.randn(B, T, F, generator=g) * 2.0 - 3.0
         sd = {k: v.cpu().numpy() for k, v in m.state_dict().items()}
         want, _ = co.classify(sd, co.ModelCfg(F, H, L, int(bi), lin_h, lin_l, 0.01), feats.numpy())
-        for mode in (("f16x3", "bf16x6", "f32") if case < 8 else ("f16x3",)):
+        for mode in (("f16x3", "f32") if case < 8 else ("f16x3",)):
             m.runtime(dev).set_gemm_mode(mode)
             logits, _ = m.forward_logits(feats.to(dev))
             err = float(np.abs(logits.cpu().numpy() - want).max())

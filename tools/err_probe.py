@@ -1,36 +1,60 @@
 #!/usr/bin/env python3
-"""Where does the logit error come from?  GPU vs fp32 torch-CPU reference vs the double-accumulating C oracle
-on bench-like inputs (identical features for all three).  Run on the GPU box."""
-import os, sys
+"""Where does the logit error come from?  GPU (both GEMM modes) and the fp32 torch-CPU reference path against a float64
+evaluation of the same network, on IDENTICAL features, at BASELINE cfg-2 scale.  Run on the GPU box.
+
+    python tools/err_probe.py [--batch 256] [--scales 4,2,1] [--seeds 42,43] [--lib path/to/other/libuvad.so]
+
+--lib loads another build of the library (e.g. one compiled with -DUVAD_FAST_GATES, the round-1 gate functions) so that
+two builds can be compared on one box; it patches the binding's path for this process only."""
+import argparse, json, os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import uvad_amd
-from uvad_amd.synth import seed_weights, synth_pcm_device
-from oracle import c_oracle as co, torch_ref as tr
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--scales", default="4,2,1")
+ap.add_argument("--seeds", default="42")
+ap.add_argument("--lib", default=None)
+ap.add_argument("--threads", type=int, default=16)
+ap.add_argument("--json", default=None)
+args = ap.parse_args()
+
+import uvad_amd
+from uvad_amd import _lib
+if args.lib:
+    _lib.LIB_PATH = os.path.abspath(args.lib)
+from uvad_amd.synth import seed_weights, synth_pcm_device
+from oracle import torch_ref as tr, parity_stats as ps
+
+torch.set_num_threads(args.threads)
 dev = torch.device("cuda:0")
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-scale = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
-F = 64
-m = uvad_amd.PyanNet2(encoding_dim=F); m.build(); seed_weights(m, 1234, scale)
-m.attach_fbank(uvad_amd.FbankConfig(num_filters=F, window_type="hamming")); m = m.to(dev).eval()
-rt = m.runtime(dev)
-pcm = synth_pcm_device(B, 160000, seed=42, device=dev)
-feats = rt.fbank(pcm)
-gls = {}
-for mode in ("f32", "bf16x6", "f16x3"):
-    rt.set_gemm_mode(mode)
-    g_, _ = rt.classify(feats, want_probs=False)
-    gls[mode] = g_.cpu().numpy()
-gl = gls["f16x3"]
-cpu = tr.TorchPyanNet2(F); cpu.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
-fc = feats.cpu()
-rl = cpu(fc)[0].numpy()
-sd = {k: v.cpu().numpy() for k, v in m.state_dict().items()}
-ol, _ = co.classify(sd, co.ModelCfg(F, 128, 4, 1, 128, 2, 0.01), fc.numpy())
-print(f"B={B} scale={scale}: logits range {ol.min():.2f}..{ol.max():.2f}")
-print(f"  |GPU - oracle(f64 acc)| = {np.abs(gl-ol).max():.2e}   |CPU fp32 - oracle| = {np.abs(rl-ol).max():.2e}   |GPU - CPU fp32| = {np.abs(gl-rl).max():.2e}")
-for mode, g_ in gls.items():
-    print(f"  gemm {mode:7s}: |GPU - oracle| max {np.abs(g_-ol).max():.2e} mean {np.abs(g_-ol).mean():.2e}   |GPU - CPU fp32| max {np.abs(g_-rl).max():.2e} mean {np.abs(g_-rl).mean():.2e}")
-print(f"  mean abs: GPU-oracle {np.abs(gl-ol).mean():.2e}  CPU-oracle {np.abs(rl-ol).mean():.2e}")
+F, B = 64, args.batch
+rows = []
+for scale in [float(x) for x in args.scales.split(",")]:
+    for seed in [int(x) for x in args.seeds.split(",")]:
+        m = uvad_amd.PyanNet2(encoding_dim=F); m.build(); seed_weights(m, 1234, scale)
+        m.attach_fbank(uvad_amd.FbankConfig(num_filters=F, window_type="hamming")); m = m.to(dev).eval()
+        rt = m.runtime(dev)
+        pcm = synth_pcm_device(B, 160000, seed=seed, device=dev)
+        feats = rt.fbank(pcm)
+        fc = feats.cpu()
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        t = time.time(); truth = ps.truth_logits(sd, fc, F); t64 = time.time() - t
+        cpu = tr.TorchPyanNet2(F); cpu.load_state_dict(sd)
+        t = time.time(); ref = cpu(fc)[0].numpy(); t32 = time.time() - t
+        st_cpu = ps.error_stats(ref, truth)
+        print(f"scale x{scale:g} seed {seed} B={B}: logits {truth.min():.2f}..{truth.max():.2f}  (torch f64 {t64:.1f} s, f32 {t32:.1f} s)")
+        print("  " + ps.fmt("CPU fp32 vs f64      ", st_cpu))
+        for mode in ("f16x3", "f32"):
+            rt.set_gemm_mode(mode)
+            g, _ = rt.classify(feats, want_probs=False)
+            g = g.cpu().numpy()
+            st = ps.error_stats(g, truth)
+            st2 = ps.error_stats(g, ref)
+            print("  " + ps.fmt(f"GPU {mode:5s} vs f64     ", st) + f"   ratio to CPU: max {st['max']/st_cpu['max']:.2f} rms {st['rms']/st_cpu['rms']:.2f} mean {st['mean']/st_cpu['mean']:.2f}")
+            print("  " + ps.fmt(f"GPU {mode:5s} vs CPU fp32", st2))
+            rows.append({"scale": scale, "seed": seed, "mode": mode, "gpu_vs_f64": st, "cpu_vs_f64": st_cpu, "gpu_vs_cpu": st2})
+        rt.close()
+if args.json:
+    json.dump({"lib": args.lib or "default", "batch": B, "rows": rows}, open(args.json, "w"), indent=1)

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libuvad.so")
 
 UVAD_OK = 0
 ERR_NAMES = {-1: "UVAD_E_ARG", -2: "UVAD_E_HIP", -3: "UVAD_E_STATE", -4: "UVAD_E_WORKSPACE", -5: "UVAD_E_UNSUPPORTED"}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class FbankCfg(C.Structure):
@@ -67,6 +67,9 @@ SIGNATURES = {
     "uvad_label_runs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uvad_der_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "uvad_set_gemm_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "uvad_set_recurrent_tile": (C.c_int, [C.c_void_p, C.c_int]),
+    "uvad_get_recurrent_tile": (C.c_int, [C.c_void_p]),
+    "uvad_streams_overlap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "uvad_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "uvad_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "uvad_last_error": (C.c_char_p, [C.c_void_p]),

@@ -354,8 +354,8 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
             }
             if (m < F) {
                 float *o = a.feats + ((size_t)b * a.T + t0 + fa) * F + m;
-                o[0] = __logf(fmaxf(ea, a.log_floor));
-                if (has_b) o[F] = __logf(fmaxf(eb, a.log_floor));
+                o[0] = logf(fmaxf(ea, a.log_floor));   // ocml logf (<= 1 ulp), not the 2-ulp-of-log2 __logf: two per lane and frame pair, nothing next to the FFT
+                if (has_b) o[F] = logf(fmaxf(eb, a.log_floor));
             }
         }
         wave_lds_fence();

@@ -42,17 +42,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a, int mt, int n
     __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
 
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch, speed only).
+    if (a.gate && (*a.gate != 0) != (a.gate_run_if_set != 0)) return;   // device-side kernel selection (see GemmArgs)
     const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
     const int m_tile = (idx / nt) * 8 + xcd, n_tile = idx % nt;
     if (m_tile >= mt) return;
-    int R0 = m_tile * BM, Rend = a.M;
-    if (a.a_mode == 2) {   // time window of the tile-major matrix (see GemmArgs)
-        const int nblk = (a.win_tc * SEQ_TILE + BM - 1) / BM;
-        const int tile = m_tile / nblk, blk = m_tile - tile * nblk;
-        R0 = (tile * a.T + a.win_t0) * SEQ_TILE + blk * BM;
-        Rend = (tile * a.T + a.win_t0 + a.win_tc) * SEQ_TILE;
-    }
+    const int R0 = m_tile * BM, Rend = a.M;
     const int C0 = n_tile * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,15 +71,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a, int mt, int n
     for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
 
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    // A columns past K (only in the last K-step when K % 32 != 0) re-read column block 0: finite
-    // values that meet zero weights.
+    // A columns past K (only in the last K-step when K % 32 != 0): the load re-reads column block 0 (unconditional,
+    // in bounds) and the registers are zeroed (a non-finite value there must not meet the zero-padded weights).
 #define UVAD_GLOAD(k0)                                                        \
     {                                                                         \
-        const int ka_ = ((k0) + skq * 4 < a.K) ? (k0) : -skq * 4;             \
+        const bool kin_ = (k0) + skq * 4 < a.K;                               \
+        const int ka_ = kin_ ? (k0) : -skq * 4;                               \
+        const float4 z4_ = make_float4(0.f, 0.f, 0.f, 0.f);                   \
         ra0 = *reinterpret_cast<const float4 *>(ap0 + ka_);                   \
         ra1 = *reinterpret_cast<const float4 *>(ap1 + ka_);                   \
         ra2 = *reinterpret_cast<const float4 *>(ap2 + ka_);                   \
         ra3 = *reinterpret_cast<const float4 *>(ap3 + ka_);                   \
+        if (!kin_) { ra0 = z4_; ra1 = z4_; ra2 = z4_; ra3 = z4_; }            \
         rb0 = *reinterpret_cast<const float4 *>(bp0 + (k0));                  \
         rb1 = *reinterpret_cast<const float4 *>(bp1 + (k0));                  \
         rb2 = *reinterpret_cast<const float4 *>(bp2 + (k0));                  \
@@ -174,7 +172,7 @@ int gemm_padded_k(int K) { return (K + BK - 1) / BK * BK; }
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     if (a.ldw < gemm_padded_k(a.K)) return hipErrorInvalidValue;
-    const int mt = a.a_mode == 2 ? a.win_tiles * ((a.win_tc * SEQ_TILE + BM - 1) / BM) : (a.M + BM - 1) / BM;
+    const int mt = (a.M + BM - 1) / BM;
     const int nt = (a.N + BN - 1) / BN;
     if (mt <= 0) return hipSuccess;
     const int grid = ((mt + 7) / 8) * 8 * nt;

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void classifier_kernel(ClsArgs a) {
             const float logit = acc + a.b[0];
             const size_t o = (size_t)b * a.ld_out + t;
             if (a.logits) a.logits[o] = logit;
-            if (a.probs) a.probs[o] = 1.0f / (1.0f + __expf(-logit));
+            if (a.probs) a.probs[o] = 1.0f / (1.0f + expf(-logit));
         }
     }
 }
@@ -148,7 +148,45 @@ __global__ __launch_bounds__(256) void runs_kernel(const uint8_t *labels, int B,
     }
 }
 
+// *flag |= 1 when a value is non-finite or |x| >= limit (flag zeroed by the launcher's memset node)
+__global__ __launch_bounds__(256) void range_flag_kernel(const float *x, size_t n, float limit, int *flag) {
+    bool bad = false;
+    const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        bad |= !(__builtin_fabsf(v.x) < limit) | !(__builtin_fabsf(v.y) < limit) | !(__builtin_fabsf(v.z) < limit) | !(__builtin_fabsf(v.w) < limit);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= !(__builtin_fabsf(x[n4 * 4 + threadIdx.x]) < limit);   // NaN compares false
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// busy-waits `ticks` of the constant 100 MHz counter (s_memrealtime), one wave: the stream-overlap probe's "long" kernel
+__global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks, unsigned long long *sink) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t = t0;
+    while (t - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        t = __builtin_amdgcn_s_memrealtime();
+    }
+    if (sink && threadIdx.x == 0) *sink = t - t0;
+}
+
 }  // namespace
+
+hipError_t launch_spin(unsigned long long ticks, unsigned long long *sink, hipStream_t s) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, ticks, sink);
+    return hipGetLastError();
+}
+
+hipError_t launch_range_flag(const float *x, size_t n, float limit, int *flag, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    if (n == 0) return hipSuccess;
+    const size_t want = (n / 4 + 255) / 256;
+    const int grid = (int)(want < 1 ? 1 : want > 2048 ? 2048 : want);
+    hipLaunchKernelGGL(range_flag_kernel, dim3(grid), dim3(256), 0, s, x, n, limit, flag);
+    return hipGetLastError();
+}
 
 hipError_t launch_runs(const uint8_t *labels, int B, int T, int max_runs, int *runs, int *counts, hipStream_t s) {
     if (B <= 0 || T <= 0) return hipSuccess;

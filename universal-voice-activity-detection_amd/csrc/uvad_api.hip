@@ -22,7 +22,6 @@ struct HostTensor {
 
 struct LayerDev {
     float *w_ih = nullptr;   // [dirs*4H (permuted: dir, unit, gate)][in]
-    unsigned short *w_ih_split = nullptr;   // the same as three bf16 planes (gemm_split.hip)
     unsigned short *w_ih_split16 = nullptr; // the same as two f16 planes (gemm_f16x3.hip)
     float *bias = nullptr;   // [dirs*4H] b_ih + b_hh, same permutation
     float *w_hh = nullptr;   // [dirs][packed register image]
@@ -47,13 +46,10 @@ struct uvad_ctx {
     int mel_stride = 0;
     std::vector<LayerDev> layers;
     std::vector<float *> lin_w, lin_b;
-    std::vector<unsigned short *> lin_w_split, lin_w_split16;
-    bool f16_ok = true;   // every GEMM weight fits the f16 range (gemm mode 2 is usable)
-    int gemm_mode = 2;   // 0: exact f32 MFMA (gemm.hip); 1: split-bf16 x6 (gemm_split.hip); 2: split-f16 x3 (gemm_f16x3.hip)
-    // overlap of layer k+1's input projection with layer k's recurrence (side stream + events)
-    int overlap = 0;     // off by default: measured neutral with the on-the-fly split GEMM (profiles/README.md); UVAD_OVERLAP=1
-    hipStream_t side = nullptr;
-    std::vector<hipEvent_t> ovl_ev;
+    std::vector<unsigned short *> lin_w_split16;
+    bool f16_ok = true;   // every GEMM operand the weights determine fits the f16 range (gemm mode 1 is usable)
+    int gemm_mode = 1;    // 0: exact f32 MFMA (gemm.hip); 1: split-f16 x3 (gemm_f16x3.hip)
+    int rec_tile_mode = 0, rec_tile_used = 0;   // sequences per recurrent workgroup: requested (0 = by batch size) / last launched
     float *cls_w = nullptr, *cls_b = nullptr;
     // SincNet front end (sincnet.hip)
     bool has_sinc = false, sinc_ready = false;
@@ -61,12 +57,12 @@ struct uvad_ctx {
     float *sn_wav_g = nullptr, *sn_wav_b = nullptr;
     float *sn_wt[3] = {nullptr, nullptr, nullptr}, *sn_bias[3] = {nullptr, nullptr, nullptr};
     float *sn_g[3] = {nullptr, nullptr, nullptr}, *sn_b[3] = {nullptr, nullptr, nullptr};
-    std::vector<void *> allocs;
+    std::vector<void *> allocs;          // feature tables, twiddles: live as long as the context
+    std::vector<void *> weight_allocs;   // everything uvad_finalize uploads: replaced by the next uvad_finalize
     // timing
     bool timing = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
-    float proj_ms = 0.f, rec_ms = 0.f;
     std::vector<hipEvent_t> layer_ev;
 };
 
@@ -88,10 +84,10 @@ int hip_fail(uvad_ctx *c, hipError_t e, const char *what) {
 size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 template <typename T>
-int dev_upload(uvad_ctx *c, const T *host, size_t n, T **out) {
+int dev_upload(uvad_ctx *c, const T *host, size_t n, T **out, bool weight = false) {
     void *p = nullptr;
     HIPCHK(c, hipMalloc(&p, n * sizeof(T) ? n * sizeof(T) : sizeof(T)));
-    c->allocs.push_back(p);
+    (weight ? c->weight_allocs : c->allocs).push_back(p);
     if (n) HIPCHK(c, hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
     *out = reinterpret_cast<T *>(p);
     return UVAD_OK;
@@ -101,12 +97,7 @@ int dev_upload(uvad_ctx *c, const T *host, size_t n, T **out) {
 struct WsLayout {
     int tiles = 0, D = 0, Wd = 0;
     size_t M = 0;
-    // off_G[set][dir]: gate pre-activation buffers.  Classic path: only [0][0].  Overlapped path: layer k
-    // reads the partial sums of set k&1 (one per direction of the layer below) while the projections of
-    // layer k+1 are written into set (k+1)&1.
-    size_t off_G[2][2] = {{0, 0}, {0, 0}}, off_Y[2] = {0, 0}, off_Z[2] = {0, 0}, off_feats = 0, off_state[2] = {0, 0}, total = 0;
-    bool overlap = false;
-    int chunk = 0, n_chunks = 1;
+    size_t off_G = 0, off_Y[2] = {0, 0}, off_Z[2] = {0, 0}, off_feats = 0, off_flag = 0, total = 0;
 };
 WsLayout carve(const uvad_ctx *c, int B, int64_t T) {
     WsLayout w;
@@ -115,22 +106,12 @@ WsLayout carve(const uvad_ctx *c, int B, int64_t T) {
     w.D = m.bidirectional ? 2 : 1;
     w.Wd = m.hidden * w.D;
     w.M = (size_t)w.tiles * SEQ_TILE * (size_t)T;
-    // Overlap pays when the recurrence leaves CUs idle (one workgroup per 4 sequences and direction) and
-    // the sequence is long enough to cut into chunks whose projection tiles are whole (multiples of 32 frames).
-    w.overlap = c->overlap && m.num_layers >= 2 && T >= 256 && w.tiles * w.D <= 144;
-    if (w.overlap) {
-        static const int want_chunks = [] { const char *e = std::getenv("UVAD_OVL_CHUNKS"); const int v = e ? std::atoi(e) : 8; return v >= 1 && v <= 8 ? v : 8; }();
-        w.chunk = (int)(((T + want_chunks - 1) / want_chunks + 31) / 32 * 32);
-        w.n_chunks = (int)((T + w.chunk - 1) / w.chunk);
-    }
     size_t o = 0;
-    const size_t gbytes = align_up(w.M * 4 * m.hidden * w.D * sizeof(float));
-    for (int set = 0; set < (w.overlap ? 2 : 1); ++set)
-        for (int d = 0; d < (w.overlap ? w.D : 1); ++d) { w.off_G[set][d] = o; o += gbytes; }
-    for (int i = 0; i < 2; ++i) { w.off_state[i] = o; o += align_up((size_t)w.D * w.tiles * SEQ_TILE * m.hidden * sizeof(float)); }
+    w.off_G = o; o += align_up(w.M * 4 * m.hidden * w.D * sizeof(float));
     for (int i = 0; i < 2; ++i) { w.off_Y[i] = o; o += align_up(w.M * w.Wd * sizeof(float)); }
     for (int i = 0; i < 2; ++i) { w.off_Z[i] = o; o += align_up(w.M * (size_t)(m.lin_layers > 0 ? m.lin_hidden : 0) * sizeof(float)); }
     w.off_feats = o; o += align_up((size_t)B * T * (size_t)(c->has_fb && c->fb.n_mels > m.in_dim ? c->fb.n_mels : m.in_dim) * sizeof(float));
+    w.off_flag = o; o += align_up(sizeof(int));   // device-side "features outside the f16 range" flag (uvad_classify)
     w.total = o;
     return w;
 }
@@ -254,8 +235,6 @@ int uvad_create(int device, const uvad_fbank_cfg *fb, const uvad_model_cfg *mode
             return fail(c, UVAD_E_ARG, "bad model configuration");
     }
     for (auto &ev : c->ev) HIPCHK(c, hipEventCreate(&ev));
-    if (const char *e = std::getenv("UVAD_GEMM")) c->gemm_mode = std::strcmp(e, "f32") == 0 ? 0 : std::strcmp(e, "bf16x6") == 0 ? 1 : 2;
-    if (const char *e = std::getenv("UVAD_OVERLAP")) c->overlap = std::strcmp(e, "0") == 0 ? 0 : 1;
     return UVAD_OK;
 }
 
@@ -303,10 +282,33 @@ int uvad_set_weight(uvad_ctx *c, const char *torch_key, const float *host, const
     return UVAD_OK;
 }
 
+extern "C++" {
+namespace {
+void free_weights(uvad_ctx *c) {
+    for (void *p : c->weight_allocs) (void)hipFree(p);
+    c->weight_allocs.clear();
+    for (auto &ev : c->layer_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    c->layer_ev.clear();
+    c->layers.clear();
+    c->lin_w.clear(); c->lin_b.clear(); c->lin_w_split16.clear();
+    c->cls_w = c->cls_b = nullptr;
+    c->sn_wav_g = c->sn_wav_b = nullptr;
+    for (int i = 0; i < 3; ++i) c->sn_wt[i] = c->sn_bias[i] = c->sn_g[i] = c->sn_b[i] = nullptr;
+    c->sinc_ready = false;
+    c->finalized = false;
+}
+}  // namespace
+}  // extern "C++"
+
 int uvad_finalize(uvad_ctx *c) {
     if (!c) return UVAD_E_ARG;
     if (!c->has_model) return fail(c, UVAD_E_STATE, "no model configuration");
     HIPCHK(c, hipSetDevice(c->device));
+    // Idempotent: a second call (e.g. after swapping weights with uvad_set_weight) replaces the previous upload.
+    // Kernels of earlier calls may still be reading the old buffers.
+    if (!c->weight_allocs.empty()) HIPCHK(c, hipDeviceSynchronize());
+    free_weights(c);
     const uvad_model_cfg &m = c->mc;
     const int H = m.hidden, D = m.bidirectional ? 2 : 1;
     auto get = [&](const std::string &k) -> const HostTensor * {
@@ -341,26 +343,23 @@ int uvad_finalize(uvad_ctx *c) {
         LayerDev &L = c->layers[k];
         L.in = in;
         int r;
-        if ((r = dev_upload(c, wp.data(), wp.size(), &L.w_ih))) return r;
-        {
-            std::vector<unsigned short> sp(3 * wp.size());
-            split_weights_bf16x3(wp.data(), wp.size(), sp.data());
-            if ((r = dev_upload(c, sp.data(), sp.size(), &L.w_ih_split))) return r;
-        }
+        if ((r = dev_upload(c, wp.data(), wp.size(), &L.w_ih, true))) return r;
         {
             std::vector<unsigned short> sp(2 * wp.size());
             if (!split_weights_f16x2(wp.data(), wp.size(), sp.data())) c->f16_ok = false;
-            if ((r = dev_upload(c, sp.data(), sp.size(), &L.w_ih_split16))) return r;
+            if ((r = dev_upload(c, sp.data(), sp.size(), &L.w_ih_split16, true))) return r;
         }
-        if ((r = dev_upload(c, bp.data(), bp.size(), &L.bias))) return r;
-        if ((r = dev_upload(c, hh.data(), hh.size(), &L.w_hh))) return r;
-        if (H == 128 && (r = dev_upload(c, hh16.data(), hh16.size(), &L.w_hh16))) return r;
+        if ((r = dev_upload(c, bp.data(), bp.size(), &L.bias, true))) return r;
+        if ((r = dev_upload(c, hh.data(), hh.size(), &L.w_hh, true))) return r;
+        if (H == 128 && (r = dev_upload(c, hh16.data(), hh16.size(), &L.w_hh16, true))) return r;
     }
     c->lin_w.assign(m.lin_layers, nullptr);
     c->lin_b.assign(m.lin_layers, nullptr);
-    c->lin_w_split.assign(m.lin_layers, nullptr);
     c->lin_w_split16.assign(m.lin_layers, nullptr);
     int prev = H * D;
+    // Static bound on what the feed-forward GEMMs can be fed: |h| < 1 out of the LSTM, so |z_j| <= sum_k |w_jk| * amax + |b_j|
+    // (leaky_relu does not grow magnitudes for slopes in [-1, 1]).  If that can leave the f16 range the split-f16 GEMM is not used.
+    double amax = 1.0;
     for (int j = 0; j < m.lin_layers; ++j) {
         const HostTensor *w = get("linear." + std::to_string(j) + ".weight"), *b = get("linear." + std::to_string(j) + ".bias");
         if (!w || !b) return fail(c, UVAD_E_STATE, "missing linear." + std::to_string(j));
@@ -369,39 +368,39 @@ int uvad_finalize(uvad_ctx *c) {
         int r;
         const int prevp = gemm_padded_k(prev);
         std::vector<float> wpad((size_t)m.lin_hidden * prevp, 0.0f);
-        for (int o = 0; o < m.lin_hidden; ++o) std::memcpy(&wpad[(size_t)o * prevp], &w->data[(size_t)o * prev], sizeof(float) * prev);
-        if ((r = dev_upload(c, wpad.data(), wpad.size(), &c->lin_w[j]))) return r;
-        {
-            std::vector<unsigned short> sp(3 * wpad.size());
-            split_weights_bf16x3(wpad.data(), wpad.size(), sp.data());
-            if ((r = dev_upload(c, sp.data(), sp.size(), &c->lin_w_split[j]))) return r;
+        double zmax = 0.0;
+        for (int o = 0; o < m.lin_hidden; ++o) {
+            std::memcpy(&wpad[(size_t)o * prevp], &w->data[(size_t)o * prev], sizeof(float) * prev);
+            double l1 = 0.0;
+            for (int k = 0; k < prev; ++k) l1 += std::fabs((double)w->data[(size_t)o * prev + k]);
+            const double z = l1 * amax + std::fabs((double)b->data[o]);
+            if (!(z <= zmax)) zmax = z;   // NaN-propagating max
         }
+        if ((r = dev_upload(c, wpad.data(), wpad.size(), &c->lin_w[j], true))) return r;
         {
             std::vector<unsigned short> sp(2 * wpad.size());
             if (!split_weights_f16x2(wpad.data(), wpad.size(), sp.data())) c->f16_ok = false;
-            if ((r = dev_upload(c, sp.data(), sp.size(), &c->lin_w_split16[j]))) return r;
+            if ((r = dev_upload(c, sp.data(), sp.size(), &c->lin_w_split16[j], true))) return r;
         }
-        if ((r = dev_upload(c, b->data.data(), b->data.size(), &c->lin_b[j]))) return r;
+        if ((r = dev_upload(c, b->data.data(), b->data.size(), &c->lin_b[j], true))) return r;
+        amax = zmax * std::fmax(1.0, std::fabs((double)m.leaky_slope));
+        if (j + 1 < m.lin_layers && !(amax < 65504.0)) c->f16_ok = false;   // the next feed-forward GEMM would see it
         prev = m.lin_hidden;
     }
     const HostTensor *cw = get("classifier.weight"), *cb = get("classifier.bias");
     if (!cw || !cb) return fail(c, UVAD_E_STATE, "missing classifier tensors");
     if (!expect_shape(*cw, {1, prev}) || !expect_shape(*cb, {1})) return fail(c, UVAD_E_ARG, "classifier shape mismatch");
     int r;
-    if ((r = dev_upload(c, cw->data.data(), cw->data.size(), &c->cls_w))) return r;
-    if ((r = dev_upload(c, cb->data.data(), cb->data.size(), &c->cls_b))) return r;
-    c->layer_ev.resize((size_t)2 * m.num_layers + 2);
+    if ((r = dev_upload(c, cw->data.data(), cw->data.size(), &c->cls_w, true))) return r;
+    if ((r = dev_upload(c, cb->data.data(), cb->data.size(), &c->cls_b, true))) return r;
+    c->layer_ev.assign((size_t)2 * m.num_layers + 2, nullptr);
     for (auto &ev : c->layer_ev) HIPCHK(c, hipEventCreate(&ev));
-    if (c->overlap && !c->side) HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));   // only the optional overlap path uses it (streams share few hardware queues)
-    c->ovl_ev.resize((size_t)m.num_layers * 9 + 2);
-    for (auto &ev : c->ovl_ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    c->sinc_ready = false;
     if (c->has_sinc && get("sincnet.conv1d.0.filters")) {   // the stage is optional: packed only when its tensors were given
         const uvad_sincnet_cfg &q = c->sc;
         const HostTensor *wg = get("sincnet.wav_norm1d.weight"), *wb = get("sincnet.wav_norm1d.bias");
         if (!wg || !wb || !expect_shape(*wg, {1}) || !expect_shape(*wb, {1})) return fail(c, UVAD_E_STATE, "missing / misshaped sincnet.wav_norm1d tensors");
-        if ((r = dev_upload(c, wg->data.data(), 1, &c->sn_wav_g))) return r;
-        if ((r = dev_upload(c, wb->data.data(), 1, &c->sn_wav_b))) return r;
+        if ((r = dev_upload(c, wg->data.data(), 1, &c->sn_wav_g, true))) return r;
+        if ((r = dev_upload(c, wb->data.data(), 1, &c->sn_wav_b, true))) return r;
         const int cin[3] = {1, q.n_filters, q.c2}, cout[3] = {q.n_filters, q.c2, q.c3}, kw[3] = {q.kernel_size, q.k2, q.k3};
         for (int i = 0; i < 3; ++i) {
             const std::string id = std::to_string(i);
@@ -421,10 +420,10 @@ int uvad_finalize(uvad_ctx *c) {
                         wt[(size_t)(t * cin[i] + ci) * NW + n] = w->data[((size_t)n * cin[i] + ci) * kw[i] + t];
                 if (b) bias[n] = b->data[n];
             }
-            if ((r = dev_upload(c, wt.data(), wt.size(), &c->sn_wt[i]))) return r;
-            if ((r = dev_upload(c, bias.data(), bias.size(), &c->sn_bias[i]))) return r;
-            if ((r = dev_upload(c, g->data.data(), g->data.size(), &c->sn_g[i]))) return r;
-            if ((r = dev_upload(c, be->data.data(), be->data.size(), &c->sn_b[i]))) return r;
+            if ((r = dev_upload(c, wt.data(), wt.size(), &c->sn_wt[i], true))) return r;
+            if ((r = dev_upload(c, bias.data(), bias.size(), &c->sn_bias[i], true))) return r;
+            if ((r = dev_upload(c, g->data.data(), g->data.size(), &c->sn_g[i], true))) return r;
+            if ((r = dev_upload(c, be->data.data(), be->data.size(), &c->sn_b[i], true))) return r;
         }
         c->sinc_ready = true;
     }
@@ -511,7 +510,7 @@ int uvad_sincnet(uvad_ctx *c, const float *d_wav, int B, int64_t S, float *d_fea
 }
 
 static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float *d_logits, float *d_probs,
-                         void *ws, size_t ws_bytes, hipStream_t s, bool record_start,
+                         void *ws, size_t ws_bytes, hipStream_t s, bool record_start, bool check_range,
                          const StreamState *ss, int ld_out);
 
 int uvad_forward_wav(uvad_ctx *c, const float *d_wav, int B, int64_t S, float *d_logits, float *d_probs,
@@ -532,7 +531,7 @@ int uvad_forward_wav(uvad_ctx *c, const float *d_wav, int B, int64_t S, float *d
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
     int r = sincnet_impl(c, d_wav, B, S, feats, base + w.total, ws_bytes - w.total, s);
     if (r) return r;
-    return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, w.total, s, false, nullptr, 0);
+    return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, w.total, s, false, true, nullptr, 0);
 }
 
 int64_t uvad_num_frames(const uvad_ctx *c, int64_t S) {
@@ -551,6 +550,7 @@ static int fbank_impl(uvad_ctx *c, const void *d_pcm, int is_i16, int B, int64_t
     if (!c->has_fb || !c->tables_set) return fail(c, UVAD_E_STATE, "uvad_fbank: uvad_set_tables has not been called");
     const int64_t T = uvad_num_frames(c, S);
     if (T <= 0) return fail(c, UVAD_E_ARG, "uvad_fbank: input shorter than one frame");
+    HIPCHK(c, hipSetDevice(c->device));
     if (B > 65535) return fail(c, UVAD_E_UNSUPPORTED, "uvad_fbank: B > 65535 (grid.y); split the batch");
     FbankArgs a{};
     a.pcm = d_pcm; a.pcm_is_i16 = is_i16; a.B = B; a.S = S; a.T = T;
@@ -570,8 +570,11 @@ int uvad_fbank_i16(uvad_ctx *c, const int16_t *d_pcm, int B, int64_t S, float *d
     return fbank_impl(c, d_pcm, 1, B, S, d_feats, stream);
 }
 
+// check_range: the features come from the caller (or from a front end with learnable scales) and may lie outside the f16
+// range; the split-f16 layer-0 projection is then replaced by the exact-f32 one ON THE DEVICE (both are enqueued, a flag
+// written by range_flag_kernel lets exactly one of them run), so the call stays asynchronous and capturable.
 static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float *d_logits, float *d_probs,
-                         void *ws, size_t ws_bytes, hipStream_t s, bool record_start,
+                         void *ws, size_t ws_bytes, hipStream_t s, bool record_start, bool check_range,
                          const StreamState *ss = nullptr, int ld_out = 0) {
     const uvad_model_cfg &m = c->mc;
     const WsLayout w = carve(c, B, T);
@@ -580,95 +583,40 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
     char *base = reinterpret_cast<char *>(ws);
     float *Y[2] = {reinterpret_cast<float *>(base + w.off_Y[0]), reinterpret_cast<float *>(base + w.off_Y[1])};
     float *Z[2] = {reinterpret_cast<float *>(base + w.off_Z[0]), reinterpret_cast<float *>(base + w.off_Z[1])};
+    float *G = reinterpret_cast<float *>(base + w.off_G);
+    int *flag = reinterpret_cast<int *>(base + w.off_flag);
     const int H = m.hidden, D = w.D, N4 = 4 * H * D;
-    auto Gbuf = [&](int set, int d) { return reinterpret_cast<float *>(base + w.off_G[set][d]); };
-    // mode 2 falls back to the bf16 split when a weight does not fit the f16 range (never the case for trained VAD weights)
-    const int gmode = c->gemm_mode == 2 && !c->f16_ok ? 1 : c->gemm_mode;
-    auto run_gemm = [&](const GemmArgs &g, hipStream_t st) {
-        return gmode == 2 ? launch_gemm_f16x3(g, st) : gmode == 1 ? launch_gemm_split(g, st) : launch_gemm(g, st);
-    };
+    // the split-f16 GEMM needs operands inside the f16 range: weights were checked by uvad_finalize (f16_ok)
+    const bool f16 = c->gemm_mode == 1 && c->f16_ok;
+    auto run_gemm = [&](const GemmArgs &g) { return f16 ? launch_gemm_f16x3(g, s) : launch_gemm(g, s); };
     if (c->timing && record_start) HIPCHK(c, hipEventRecord(c->ev[0], s));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
-    const bool overlap = w.overlap && !ss;
-    if (!overlap) {
-        float *G = Gbuf(0, 0);
-        for (int k = 0; k < m.num_layers; ++k) {
-            const LayerDev &L = c->layers[k];
-            GemmArgs g{};
-            g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.Wsplit = L.w_ih_split; g.Wsplit16 = L.w_ih_split16; g.bias = L.bias; g.C = G;
-            g.M = (int)w.M; g.N = N4; g.K = L.in; g.ldc = N4; g.B = B; g.T = T; g.act = 0; g.leaky_slope = 0.f;
-            if (k == 0) { g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1; }
-            else { g.A = Y[(k - 1) & 1]; g.lda = w.Wd; g.a_mode = 0; }
-            if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k], s));
-            HIPCHK(c, run_gemm(g, s));
-            if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k + 1], s));
-            LstmArgs r{};
-            r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.Whh_packed16 = L.w_hh16; r.Y = Y[k & 1]; r.ldy = w.Wd;
-            r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D;
-            if (ss) {   // carried (h, c) of this layer, updated in place
-                r.h0 = r.hN = ss->h + (size_t)k * ss->layer_stride;
-                r.c0 = r.cN = ss->c + (size_t)k * ss->layer_stride;
-            }
-            HIPCHK(c, launch_lstm(r, s));
+    for (int k = 0; k < m.num_layers; ++k) {
+        const LayerDev &L = c->layers[k];
+        GemmArgs g{};
+        g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.Wsplit16 = L.w_ih_split16; g.bias = L.bias; g.C = G;
+        g.M = (int)w.M; g.N = N4; g.K = L.in; g.ldc = N4; g.B = B; g.T = T; g.act = 0; g.leaky_slope = 0.f;
+        if (k == 0) { g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1; }
+        else { g.A = Y[(k - 1) & 1]; g.lda = w.Wd; g.a_mode = 0; }
+        if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k], s));
+        if (k == 0 && f16 && check_range) {
+            HIPCHK(c, launch_range_flag(d_feats, (size_t)B * T * m.in_dim, 65504.0f, flag, s));
+            g.gate = flag; g.gate_run_if_set = 0;
+            HIPCHK(c, launch_gemm_f16x3(g, s));
+            g.gate_run_if_set = 1;
+            HIPCHK(c, launch_gemm(g, s));
+        } else {
+            HIPCHK(c, run_gemm(g));
         }
-    } else {
-        // Layer k's recurrence runs in n_chunks launches on the caller's stream, carrying (h, c) through the
-        // workspace; as soon as a chunk is done, the projection of the frames it produced -- the forward
-        // direction's K-slice of layer k+1's W_ih over the forward chunk, the reverse direction's slice over
-        // the reverse chunk -- runs on the side stream, on the CUs the recurrence leaves idle.  Layer k+1
-        // then starts from the SUM of the per-direction partials (the recurrent kernel adds them).
-        const size_t need_ev = (size_t)m.num_layers * (w.n_chunks + 1) + 2;
-        if (c->ovl_ev.size() < need_ev) return fail(c, UVAD_E_STATE, "event pool too small for this sequence length");
-        size_t evi = 0;
-        float *hst = reinterpret_cast<float *>(base + w.off_state[0]), *cst = reinterpret_cast<float *>(base + w.off_state[1]);
-        {   // layer 0: one full projection of the features
-            const LayerDev &L = c->layers[0];
-            GemmArgs g{};
-            g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.Wsplit = L.w_ih_split; g.Wsplit16 = L.w_ih_split16; g.bias = L.bias; g.C = Gbuf(0, 0);
-            g.M = (int)w.M; g.N = N4; g.K = L.in; g.ldc = N4; g.B = B; g.T = T; g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1;
-            if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[0], s));
-            HIPCHK(c, run_gemm(g, s));
-            if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[1], s));
+        if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k + 1], s));
+        LstmArgs r{};
+        r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.Whh_packed16 = L.w_hh16; r.Y = Y[k & 1]; r.ldy = w.Wd;
+        r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D; r.tile_mode = ss ? 4 : c->rec_tile_mode;
+        if (ss) {   // carried (h, c) of this layer, updated in place
+            r.h0 = r.hN = ss->h + (size_t)k * ss->layer_stride;
+            r.c0 = r.cN = ss->c + (size_t)k * ss->layer_stride;
         }
-        for (int k = 0; k < m.num_layers; ++k) {
-            const LayerDev &L = c->layers[k];
-            const int set = k & 1;
-            if (k > 0 && c->timing) {
-                HIPCHK(c, hipEventRecord(c->layer_ev[2 * k], s));
-                HIPCHK(c, hipEventRecord(c->layer_ev[2 * k + 1], s));
-            }
-            for (int ch = 0; ch < w.n_chunks; ++ch) {
-                const int sb = ch * w.chunk, sc = T - sb < w.chunk ? T - sb : w.chunk;
-                LstmArgs r{};
-                r.G = Gbuf(set, 0); r.G2 = (k > 0 && D == 2) ? Gbuf(set, 1) : nullptr; r.ldg = N4;
-                r.Whh_packed = L.w_hh; r.Y = Y[k & 1]; r.ldy = w.Wd;
-                r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D; r.s_begin = sb; r.s_count = sc;
-                r.h0 = ch == 0 ? nullptr : hst; r.c0 = ch == 0 ? nullptr : cst; r.hN = hst; r.cN = cst;
-                HIPCHK(c, launch_lstm(r, s));
-                if (k + 1 < m.num_layers) {
-                    hipEvent_t e = c->ovl_ev[evi++];
-                    HIPCHK(c, hipEventRecord(e, s));
-                    static const bool same = std::getenv("UVAD_OVL_SAMESTREAM") != nullptr;   // diagnostic: no concurrency
-                    hipStream_t gs = same ? s : c->side;
-                    HIPCHK(c, hipStreamWaitEvent(gs, e, 0));
-                    const LayerDev &Ln = c->layers[k + 1];
-                    for (int d = 0; d < D; ++d) {
-                        GemmArgs g{};
-                        g.A = Y[k & 1] + d * H; g.lda = w.Wd; g.a_mode = 2;
-                        g.W = Ln.w_ih + d * H; g.ldw = gemm_padded_k(Ln.in); g.Wsplit = Ln.w_ih_split + d * H; g.Wsplit16 = Ln.w_ih_split16 + d * H;
-                        g.bias = d == 0 ? Ln.bias : nullptr; g.C = Gbuf(set ^ 1, d);
-                        g.M = (int)w.M; g.N = N4; g.K = H; g.ldc = N4; g.B = B; g.T = T;
-                        g.win_t0 = d == 0 ? sb : T - sb - sc; g.win_tc = sc; g.win_tiles = w.tiles;
-                        HIPCHK(c, run_gemm(g, gs));
-                    }
-                }
-            }
-            if (k + 1 < m.num_layers) {   // join: every partial of layer k+1 is complete
-                hipEvent_t e = c->ovl_ev[evi++];
-                HIPCHK(c, hipEventRecord(e, c->side));
-                HIPCHK(c, hipStreamWaitEvent(s, e, 0));
-            }
-        }
+        HIPCHK(c, launch_lstm(r, s, &c->rec_tile_used));
     }
     if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * m.num_layers], s));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
@@ -678,8 +626,8 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         GemmArgs g{};
         g.A = cur; g.lda = curw; g.a_mode = 0; g.W = c->lin_w[j]; g.ldw = gemm_padded_k(curw); g.bias = c->lin_b[j]; g.C = Z[j & 1];
         g.M = (int)w.M; g.N = m.lin_hidden; g.K = curw; g.ldc = m.lin_hidden; g.B = B; g.T = T;
-        g.act = 1; g.leaky_slope = m.leaky_slope; g.Wsplit = c->lin_w_split[j]; g.Wsplit16 = c->lin_w_split16[j];
-        HIPCHK(c, run_gemm(g, s));
+        g.act = 1; g.leaky_slope = m.leaky_slope; g.Wsplit16 = c->lin_w_split16[j];
+        HIPCHK(c, run_gemm(g));
         cur = Z[j & 1];
         curw = m.lin_hidden;
     }
@@ -699,7 +647,8 @@ int uvad_classify(uvad_ctx *c, const float *d_feats, int B, int T, float *d_logi
     if (!c) return UVAD_E_ARG;
     if (!d_feats || B <= 0 || T <= 0 || !ws) return fail(c, UVAD_E_ARG, "uvad_classify: bad argument");
     if (!c->finalized) return fail(c, UVAD_E_STATE, "uvad_classify: uvad_finalize has not been called");
-    return classify_impl(c, d_feats, B, T, d_logits, d_probs, ws, ws_bytes, (hipStream_t)stream, true);
+    HIPCHK(c, hipSetDevice(c->device));
+    return classify_impl(c, d_feats, B, T, d_logits, d_probs, ws, ws_bytes, (hipStream_t)stream, true, true);
 }
 
 int uvad_forward(uvad_ctx *c, const float *d_pcm, int B, int64_t S, float *d_logits, float *d_probs,
@@ -715,15 +664,17 @@ int uvad_forward(uvad_ctx *c, const float *d_pcm, int B, int64_t S, float *d_log
     if (ws_bytes < w.total) return fail(c, UVAD_E_WORKSPACE, "workspace too small: need " + std::to_string(w.total) + " bytes");
     float *feats = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + w.off_feats);
     hipStream_t s = (hipStream_t)stream;
+    HIPCHK(c, hipSetDevice(c->device));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
     int r = fbank_impl(c, d_pcm, 0, B, S, feats, stream);
     if (r) return r;
-    return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, ws_bytes, s, false);
+    return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, ws_bytes, s, false, false);   // log-mel values are within +-90
 }
 
 int uvad_get_taps(uvad_ctx *c, int B, int T, float *d_lstm_out, float *d_lin_out, const void *ws, void *stream) {
     if (!c || !ws || B <= 0 || T <= 0) return UVAD_E_ARG;
     if (!c->finalized) return fail(c, UVAD_E_STATE, "not finalized");
+    HIPCHK(c, hipSetDevice(c->device));
     const uvad_model_cfg &m = c->mc;
     const WsLayout w = carve(c, B, T);
     const char *base = reinterpret_cast<const char *>(ws);
@@ -778,6 +729,7 @@ int uvad_stream_reset(uvad_ctx *c, void *d_state, int B, void *stream) {
     if (!c || !d_state || B <= 0) return UVAD_E_ARG;
     if (!c->has_fb || !c->has_model) return fail(c, UVAD_E_STATE, "streaming needs both a fbank and a model configuration");
     if (c->mc.bidirectional) return fail(c, UVAD_E_UNSUPPORTED, "streaming needs a causal model (lstm.bidirectional = False)");
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemsetAsync(d_state, 0, stream_layout(c, B).total, (hipStream_t)stream));
     c->streams[d_state] = StreamCounters();
     return UVAD_OK;
@@ -799,6 +751,7 @@ int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, vo
     if (ws_bytes < uvad_stream_workspace_bytes(c, B, chunk)) return fail(c, UVAD_E_WORKSPACE, "stream workspace too small");
     const StreamLayout S = stream_layout(c, B);
     hipStream_t s = (hipStream_t)stream;
+    HIPCHK(c, hipSetDevice(c->device));
     char *st = reinterpret_cast<char *>(d_state);
     char *wsb = reinterpret_cast<char *>(ws);
     float *staging = reinterpret_cast<float *>(wsb);
@@ -835,7 +788,7 @@ int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, vo
     ss.layer_stride = S.layer_stride / sizeof(float);
     const bool timing = c->timing;
     c->timing = false;
-    const int r = classify_impl(c, feats, B, k, d_logits, nullptr, cws, ws_bytes - staging_bytes, s, false, &ss, ld_logits);
+    const int r = classify_impl(c, feats, B, k, d_logits, nullptr, cws, ws_bytes - staging_bytes, s, false, false, &ss, ld_logits);
     c->timing = timing;
     return r < 0 ? r : k;
 }
@@ -843,27 +796,67 @@ int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, vo
 int uvad_median_filter(uvad_ctx *c, const float *d_probs, int B, int T, int kernel, uint8_t *d_labels, void *stream) {
     if (!c || !d_probs || !d_labels || B <= 0 || T <= 0) return UVAD_E_ARG;
     if (kernel < 1 || kernel % 2 == 0) return fail(c, UVAD_E_ARG, "median kernel must be odd");
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, launch_median(d_probs, B, T, kernel, d_labels, (hipStream_t)stream));
     return UVAD_OK;
 }
 
 int uvad_der_counts(uvad_ctx *c, const uint8_t *d_pred, const uint8_t *d_gt, int B, int T, uint32_t *d_counts, void *stream) {
     if (!c || !d_pred || !d_gt || !d_counts || B <= 0 || T <= 0) return UVAD_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, launch_der(d_pred, d_gt, B, T, d_counts, (hipStream_t)stream));
     return UVAD_OK;
 }
 
 int uvad_label_runs(uvad_ctx *c, const uint8_t *d_labels, int B, int T, int max_runs, int32_t *d_runs, int32_t *d_counts, void *stream) {
     if (!c || !d_labels || !d_runs || !d_counts || B <= 0 || T <= 0 || max_runs <= 0) return UVAD_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, launch_runs(d_labels, B, T, max_runs, d_runs, d_counts, (hipStream_t)stream));
     return UVAD_OK;
 }
 
 int uvad_set_gemm_mode(uvad_ctx *c, int mode) {
     if (!c) return UVAD_E_ARG;
-    if (mode < 0 || mode > 2) return fail(c, UVAD_E_ARG, "gemm mode must be 0 (exact f32 MFMA), 1 (split-bf16 x6) or 2 (split-f16 x3)");
+    if (mode < 0 || mode > 1) return fail(c, UVAD_E_ARG, "gemm mode must be 0 (exact f32 MFMA) or 1 (split-f16 x3)");
     c->gemm_mode = mode;
     return UVAD_OK;
+}
+
+int uvad_set_recurrent_tile(uvad_ctx *c, int sequences) {
+    if (!c) return UVAD_E_ARG;
+    if (sequences != 0 && sequences != 4 && sequences != 16) return fail(c, UVAD_E_ARG, "recurrent tile must be 0 (by batch size), 4 or 16 sequences per workgroup");
+    if (sequences == 16 && c->has_model && c->mc.hidden != 128) return fail(c, UVAD_E_UNSUPPORTED, "the 16-sequence recurrent kernel exists for hidden_size 128 only");
+    c->rec_tile_mode = sequences;
+    return UVAD_OK;
+}
+
+int uvad_get_recurrent_tile(const uvad_ctx *c) { return c ? c->rec_tile_used : UVAD_E_ARG; }
+
+int uvad_streams_overlap(uvad_ctx *c, void *stream_a, void *stream_b) {
+    if (!c) return UVAD_E_ARG;
+    if (stream_a == stream_b) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    HIPCHK(c, hipEventCreateWithFlags(&ea, hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+    int result = UVAD_E_HIP;
+    do {
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) break;
+        // 3 ms of spinning on a, then an empty spin on b: if b's kernel retires while a's is still running the two
+        // streams sit on different hardware queues; on one queue b waits behind a.
+        if (launch_spin(300000ull, nullptr, a) != hipSuccess || hipEventRecord(ea, a) != hipSuccess) break;
+        if (launch_spin(0ull, nullptr, b) != hipSuccess || hipEventRecord(eb, b) != hipSuccess) break;
+        if (hipEventSynchronize(eb) != hipSuccess) break;
+        const hipError_t q = hipEventQuery(ea);
+        if (q != hipSuccess && q != hipErrorNotReady) break;
+        result = q == hipErrorNotReady ? 1 : 0;
+        if (hipEventSynchronize(ea) != hipSuccess) result = UVAD_E_HIP;
+    } while (0);
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    if (result < 0) return fail(c, UVAD_E_HIP, "uvad_streams_overlap: HIP error while probing");
+    return result;
 }
 
 int uvad_set_timing(uvad_ctx *c, int enabled) {
@@ -896,15 +889,11 @@ const char *uvad_last_error(const uvad_ctx *c) { return c ? c->err.c_str() : "nu
 
 void uvad_destroy(uvad_ctx *c) {
     if (!c) return;
-    if (!c->allocs.empty() || c->ev[0]) (void)hipSetDevice(c->device);
+    if (!c->allocs.empty() || !c->weight_allocs.empty() || c->ev[0]) (void)hipSetDevice(c->device);
+    free_weights(c);
     for (void *p : c->allocs) (void)hipFree(p);
     for (auto &ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
-    for (auto &ev : c->layer_ev)
-        if (ev) (void)hipEventDestroy(ev);
-    for (auto &ev : c->ovl_ev)
-        if (ev) (void)hipEventDestroy(ev);
-    if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
 }
 

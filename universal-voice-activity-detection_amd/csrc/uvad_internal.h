@@ -11,14 +11,15 @@ namespace uvad {
 // so that the SEQ_TILE rows one recurrent workgroup needs at step t are adjacent in HBM.
 constexpr int SEQ_TILE = 4;
 
-// ---- gemm.hip -----------------------------------------------------------------------------
-// C[M][ldc] (cols [0,N)) = act( A[M][K] * W[N][K]^T + bias[N] ), exact f32 on v_mfma_f32_32x32x2_f32.
+// ---- gemm.hip / gemm_f16x3.hip -----------------------------------------------------------
+// C[M][ldc] (cols [0,N)) = act( A[M][K] * W[N][K]^T + bias[N] ).
+//   gemm.hip        exact f32 on v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain);
+//   gemm_f16x3.hip  f32-accurate on the f16 matrix cores with 2-way split operands.
 struct GemmArgs {
     const float *A;      // activations
     const float *W;      // [N][ldw] row-major (torch Linear / LSTM weight layout, rows possibly permuted),
                          // each row zero-padded to ldw = gemm_padded_k(K) floats
     int ldw;
-    const unsigned short *Wsplit;   // gemm_split.hip only: the same matrix as three bf16 planes [3][N][ldw]
     const unsigned short *Wsplit16; // gemm_f16x3.hip only: the same matrix as two f16 planes [2][N][ldw] (low plane x 2^11)
     const float *bias;   // [N] or nullptr
     float *C;
@@ -28,40 +29,36 @@ struct GemmArgs {
     // a_mode 1: A is canonical [B][T][K]; row m = (tile*T + t)*SEQ_TILE + j reads sequence
     //           b = tile*SEQ_TILE + j at frame t (zeros when b >= B).
     //           (rows of padded sequences and rows past the tile's range are clamped, never stored)
-    // a_mode 2: "time window" of the tile-major matrix: the M-tiles cover, for every sequence tile, the
-    //           rows of frames [win_t0, win_t0 + win_tc): block i -> tile = i / nblk, rows starting at
-    //           (tile*T + win_t0)*SEQ_TILE + (i % nblk)*128; A and C use the same row index.  Used to
-    //           project the chunk of layer outputs a recurrent launch has just produced.
     int a_mode, B, T;
-    int win_t0, win_tc, win_tiles;
     float leaky_slope;   // act: v >= 0 ? v : slope*v when act == 1
     int act;
+    // Device-side kernel selection for caller-supplied features (uvad_classify): when `gate` is set the kernel
+    // returns at once unless (*gate != 0) == gate_run_if_set.  *gate is written by launch_range_flag() earlier on
+    // the same stream, so the f16 split never sees an operand outside the f16 range and no host sync is needed.
+    const int *gate;
+    int gate_run_if_set;
 };
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t s);
 int gemm_padded_k(int K);   // K rounded up to the kernel's K-step
-// ---- gemm_split.hip: same contract on the bf16 matrix cores with 3-way split operands ("bf16x6") --
-hipError_t launch_gemm_split(const GemmArgs &a, hipStream_t s);
-void split_weights_bf16x3(const float *w, size_t n, unsigned short *out /*[3][n]*/);
-// ---- gemm_f16x3.hip: same contract on the f16 matrix cores with 2-way split operands ("f16x3": half the MFMAs of bf16x6) --
 hipError_t launch_gemm_f16x3(const GemmArgs &a, hipStream_t s);
 bool split_weights_f16x2(const float *w, size_t n, unsigned short *out /*[2][n]*/);   // false: a weight is outside the f16 range
+// *flag = 1 if any of the n values is non-finite or |x| >= limit, else 0 (one pass, async on s)
+hipError_t launch_range_flag(const float *x, size_t n, float limit, int *flag, hipStream_t s);
 
 // ---- lstm.hip -----------------------------------------------------------------------------
 // One layer, all directions: grid (tiles, dirs).  G holds x_t*W_ih^T + b_ih + b_hh with column
 // dir*4H + u*4 + gate; Y gets h_t at column dir*H + u.  Rows as above.
 struct LstmArgs {
     const float *G; int ldg;
-    const float *G2;             // optional second partial of the gate pre-activations (same layout), added to G
     const float *Whh_packed;     // per dir: register image, see pack_whh()
     const float *Whh_packed16;   // per dir: register image of the 16-sequence kernel (pack_whh16), H = 128 only
     float *Y; int ldy;
     int tiles, T, H, dirs;
-    int s_begin, s_count;        // steps [s_begin, s_begin + s_count) of the T-step recurrence (s_count 0 = all):
-                                 // forward visits t = s, reverse t = T-1-s; (h, c) carried through h0/c0 -> hN/cN
+    int tile_mode;               // sequences per workgroup: 0 = by batch size, 4, 16 (see launch_lstm)
     // optional carried state (streaming): [dirs][tiles*SEQ_TILE][H], nullptr = zeros / discard
     const float *h0, *c0; float *hN, *cN;
 };
-hipError_t launch_lstm(const LstmArgs &a, hipStream_t s);
+hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used = nullptr);
 // elements of the packed W_hh image for one direction
 size_t whh_packed_elems(int H);
 int lstm_waves(int H);   // waves per recurrent workgroup (8 at H = 128: two per SIMD)
@@ -87,6 +84,9 @@ hipError_t launch_median(const float *probs, int B, int T, int kernel, uint8_t *
 hipError_t launch_runs(const uint8_t *labels, int B, int T, int max_runs, int *runs, int *counts, hipStream_t s);
 // per-row {false alarm, missed detection} frame counts of 0/1 label rows
 hipError_t launch_der(const uint8_t *pred, const uint8_t *gt, int B, int T, uint32_t *counts, hipStream_t s);
+
+// one wave that busy-waits `ticks` of the 100 MHz constant clock, then (optionally) stores the waited ticks
+hipError_t launch_spin(unsigned long long ticks, unsigned long long *sink, hipStream_t s);
 
 // ---- fbank.hip ----------------------------------------------------------------------------
 struct FbankTables {            // device pointers owned by the ctx

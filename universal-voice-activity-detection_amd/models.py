@@ -71,11 +71,8 @@ class PyanNet2(nn.Module):
         return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _flat_state_dict(self):
-        """state_dict with the monolithic key names (``lstm.weight_ih_l{k}...``) whichever variant holds them."""
-        sd = {}
-        for k, v in self.state_dict().items():
-            sd[k] = v
-        return sd  # the C side maps ``lstm.{k}.weight_ih_l0`` -> ``lstm.weight_ih_l{k}``
+        """What goes to uvad_set_weight (the C side maps the ModuleList names ``lstm.{k}.weight_ih_l0`` -> ``lstm.weight_ih_l{k}``)."""
+        return dict(self.state_dict())
 
     def runtime(self, device):
         """The VadRuntime bound to this module's current weights on ``device`` (rebuilt if they changed)."""
@@ -84,12 +81,14 @@ class PyanNet2(nn.Module):
             raise RuntimeError("call .build() before using the model (as the reference does, vad_engine.py:42)")
         stamp = self._stamp(device)
         if self._rt is None or self._rt_stamp != stamp:
-            if self._rt is not None:
-                self._rt.close()
-            model = {"encoding_dim": self.encoding_dim, "lstm": self.hparams.lstm, "linear": self.hparams.linear}
-            rt = VadRuntime(device=device, fbank=self._fbank_cfg, model=model, **self._runtime_extra())
-            rt.load_state_dict(self._flat_state_dict())
-            self._rt, self._rt_stamp = rt, stamp
+            same_ctx = self._rt is not None and self._rt_stamp is not None and self._rt_stamp[0] == stamp[0]
+            if not same_ctx:   # first use, another device, or another feature front end: new context
+                if self._rt is not None:
+                    self._rt.close()
+                model = {"encoding_dim": self.encoding_dim, "lstm": self.hparams.lstm, "linear": self.hparams.linear}
+                self._rt = VadRuntime(device=device, fbank=self._fbank_cfg, model=model, **self._runtime_extra())
+            self._rt.load_state_dict(self._flat_state_dict())   # changed parameters: weight hot-swap (uvad_finalize replaces the upload)
+            self._rt_stamp = stamp
         return self._rt
 
     _fbank_cfg = None

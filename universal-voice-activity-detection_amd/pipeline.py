@@ -6,9 +6,10 @@ projections on the idle CUs (bench.py: 32 -> 44 M frames/s at BASELINE cfg 2).  
 (own weights copy and workspace) bound to its own stream; results are identical to the sequential path (same kernels,
 same launch shapes).
 
-Stream choice: HIP maps streams onto a small pool of hardware queues and two streams that land on one queue serialise
-(tools/overlap_probe.py), so the slots' streams are picked by a short calibration on the first batch."""
-import time
+Stream choice: HIP maps streams onto a small pool of hardware queues and two streams that land on one queue serialise.
+``select_streams`` therefore creates streams until ``depth`` of them are PROVEN pairwise concurrent by
+``uvad_streams_overlap`` (a spinning wave on one, an empty kernel on the other): an observation made once at
+construction, not a timing heuristic."""
 from typing import List, Optional
 
 import torch
@@ -31,6 +32,8 @@ class Pending:
 
 
 class ForwardPipeline:
+    MAX_STREAM_TRIES = 16
+
     def __init__(self, model, device, depth: int = 2):
         """model: a built uvad_amd.PyanNet2 with attach_fbank(...) done (weights are copied into every slot)."""
         if getattr(model, "_fbank_cfg", None) is None:
@@ -44,36 +47,32 @@ class ForwardPipeline:
             r.load_state_dict(model.state_dict())
             self.runtimes.append(r)
         self.streams: Optional[List[torch.cuda.Stream]] = None
+        self.streams_tried = 0
         self._k = 0
-        self.calibration_ms: Optional[float] = None
+        self.select_streams()
 
     # ------------------------------------------------------------------ streams
-    def _calibrate(self, pcm):
-        n = self.depth
-        cand = [torch.cuda.Stream(device=self.device) for _ in range(n + 4)]
-        if n == 1:
-            self.streams = cand[:1]
-            return
-        best = None
-        for first in range(len(cand) - n + 1):
-            sel = cand[first:first + n]
-            for _ in range(2):   # the first pass warms the selection up
-                torch.cuda.synchronize(self.device)
-                t0 = time.perf_counter()
-                for k in range(2 * n):
-                    with torch.cuda.stream(sel[k % n]):
-                        self.runtimes[k % n].forward(pcm, want_probs=False)
-                torch.cuda.synchronize(self.device)
-                dt = (time.perf_counter() - t0) / (2 * n)
-            if best is None or dt < best[0]:
-                best = (dt, sel)
-        self.calibration_ms, self.streams = best[0] * 1e3, best[1]
+    def select_streams(self) -> List[torch.cuda.Stream]:
+        """Pick ``depth`` HIP streams that are pairwise concurrent (each new candidate is probed against the ones already
+        kept).  Raises if the device offers fewer concurrent queues than ``depth``."""
+        rt = self.runtimes[0]
+        kept: List[torch.cuda.Stream] = []
+        tried = 0
+        with torch.cuda.device(self.device):
+            while len(kept) < self.depth and tried < self.MAX_STREAM_TRIES:
+                s = torch.cuda.Stream(device=self.device)
+                tried += 1
+                if all(rt.streams_overlap(k, s) for k in kept):
+                    kept.append(s)
+        self.streams_tried = tried
+        if len(kept) < self.depth:
+            raise RuntimeError(f"only {len(kept)} concurrent HIP streams found in {tried} tries; lower depth (GPU_MAX_HW_QUEUES?)")
+        self.streams = kept
+        return kept
 
     # ------------------------------------------------------------------ use
     def submit(self, pcm: torch.Tensor, want_logits: bool = True, want_probs: bool = False) -> Pending:
         """pcm (B, S) f32 on the device, ready on the CURRENT stream.  Returns at once; the step runs on the next slot's stream."""
-        if self.streams is None:
-            self._calibrate(pcm)
         i = self._k % self.depth
         self._k += 1
         s = self.streams[i]

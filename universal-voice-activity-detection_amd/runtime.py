@@ -257,9 +257,16 @@ class VadRuntime:
             return out[:, :k]
 
     def set_gemm_mode(self, mode: str):
-        """"f32": exact f32 MFMA; "bf16x6": 3-way split on the bf16 matrix cores; "f16x3": 2-way split on the f16 matrix
-        cores (default)."""
-        self._check(self.lib.uvad_set_gemm_mode(self.ctx, {"f32": 0, "bf16x6": 1, "f16x3": 2}[mode]))
+        """"f32": exact f32 MFMA; "f16x3": 2-way split on the f16 matrix cores (default)."""
+        self._check(self.lib.uvad_set_gemm_mode(self.ctx, {"f32": 0, "f16x3": 1}[mode]))
+
+    def set_recurrent_tile(self, sequences: int):
+        """Sequences per recurrent workgroup: 0 (default) = chosen from the batch size, 4 = latency form, 16 = throughput form."""
+        self._check(self.lib.uvad_set_recurrent_tile(self.ctx, int(sequences)))
+
+    def recurrent_tile(self) -> int:
+        """What the most recent classify / forward launched (4 or 16)."""
+        return int(self.lib.uvad_get_recurrent_tile(self.ctx))
 
     def der_counts(self, pred: "torch.Tensor", gt: "torch.Tensor") -> "torch.Tensor":
         """pred, gt (B, T) uint8 0/1 on the GPU -> (B, 2) int32 counts {false alarm, missed detection}."""
@@ -283,6 +290,13 @@ class VadRuntime:
             counts = torch.empty((B,), dtype=torch.int32, device=self.device)
             self._check(self.lib.uvad_label_runs(self.ctx, labels.data_ptr(), B, T, max_runs, runs.data_ptr(), counts.data_ptr(), self._stream()))
             return runs, counts
+
+    def streams_overlap(self, a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
+        """True if kernels on the two HIP streams run concurrently (they sit on different hardware queues)."""
+        r = self.lib.uvad_streams_overlap(self.ctx, C.c_void_p(a.cuda_stream), C.c_void_p(b.cuda_stream))
+        if r < 0:
+            self._check(r)
+        return r == 1
 
     def set_timing(self, on: bool):
         self._check(self.lib.uvad_set_timing(self.ctx, int(on)))
