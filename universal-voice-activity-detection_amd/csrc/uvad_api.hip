@@ -22,7 +22,8 @@ struct HostTensor {
 
 struct LayerDev {
     float *w_ih = nullptr;   // [dirs*4H (permuted: dir, unit, gate)][in]
-    unsigned short *w_ih_split16 = nullptr; // the same as two f16 planes (gemm_f16x3.hip)
+    unsigned short *w_ih_split16 = nullptr; // the same, scaled by a power of two, as three exact f16 planes (gemm_f16x3.hip)
+    float w_ih_scale = 1.0f;
     float *bias = nullptr;   // [dirs*4H] b_ih + b_hh, same permutation
     float *w_hh = nullptr;   // [dirs][packed register image]
     float *w_hh16 = nullptr; // [dirs][register image of the 16-sequence kernel] (H = 128)
@@ -47,6 +48,7 @@ struct uvad_ctx {
     std::vector<LayerDev> layers;
     std::vector<float *> lin_w, lin_b;
     std::vector<unsigned short *> lin_w_split16;
+    std::vector<float> lin_w_scale;
     bool f16_ok = true;   // every GEMM operand the weights determine fits the f16 range (gemm mode 1 is usable)
     int gemm_mode = 1;    // 0: exact f32 MFMA (gemm.hip); 1: split-f16 x3 (gemm_f16x3.hip)
     int rec_tile_mode = 0, rec_tile_used = 0;   // sequences per recurrent workgroup: requested (0 = by batch size) / last launched
@@ -291,7 +293,7 @@ void free_weights(uvad_ctx *c) {
         if (ev) (void)hipEventDestroy(ev);
     c->layer_ev.clear();
     c->layers.clear();
-    c->lin_w.clear(); c->lin_b.clear(); c->lin_w_split16.clear();
+    c->lin_w.clear(); c->lin_b.clear(); c->lin_w_split16.clear(); c->lin_w_scale.clear();
     c->cls_w = c->cls_b = nullptr;
     c->sn_wav_g = c->sn_wav_b = nullptr;
     for (int i = 0; i < 3; ++i) c->sn_wt[i] = c->sn_bias[i] = c->sn_g[i] = c->sn_b[i] = nullptr;
@@ -345,8 +347,8 @@ int uvad_finalize(uvad_ctx *c) {
         int r;
         if ((r = dev_upload(c, wp.data(), wp.size(), &L.w_ih, true))) return r;
         {
-            std::vector<unsigned short> sp(2 * wp.size());
-            if (!split_weights_f16x2(wp.data(), wp.size(), sp.data())) c->f16_ok = false;
+            std::vector<unsigned short> sp(3 * wp.size());
+            if (!split_weights_f16x3(wp.data(), wp.size(), sp.data(), &L.w_ih_scale)) c->f16_ok = false;
             if ((r = dev_upload(c, sp.data(), sp.size(), &L.w_ih_split16, true))) return r;
         }
         if ((r = dev_upload(c, bp.data(), bp.size(), &L.bias, true))) return r;
@@ -356,6 +358,7 @@ int uvad_finalize(uvad_ctx *c) {
     c->lin_w.assign(m.lin_layers, nullptr);
     c->lin_b.assign(m.lin_layers, nullptr);
     c->lin_w_split16.assign(m.lin_layers, nullptr);
+    c->lin_w_scale.assign(m.lin_layers, 1.0f);
     int prev = H * D;
     // Static bound on what the feed-forward GEMMs can be fed: |h| < 1 out of the LSTM, so |z_j| <= sum_k |w_jk| * amax + |b_j|
     // (leaky_relu does not grow magnitudes for slopes in [-1, 1]).  If that can leave the f16 range the split-f16 GEMM is not used.
@@ -378,8 +381,8 @@ int uvad_finalize(uvad_ctx *c) {
         }
         if ((r = dev_upload(c, wpad.data(), wpad.size(), &c->lin_w[j], true))) return r;
         {
-            std::vector<unsigned short> sp(2 * wpad.size());
-            if (!split_weights_f16x2(wpad.data(), wpad.size(), sp.data())) c->f16_ok = false;
+            std::vector<unsigned short> sp(3 * wpad.size());
+            if (!split_weights_f16x3(wpad.data(), wpad.size(), sp.data(), &c->lin_w_scale[j])) c->f16_ok = false;
             if ((r = dev_upload(c, sp.data(), sp.size(), &c->lin_w_split16[j], true))) return r;
         }
         if ((r = dev_upload(c, b->data.data(), b->data.size(), &c->lin_b[j], true))) return r;
@@ -594,7 +597,7 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
     for (int k = 0; k < m.num_layers; ++k) {
         const LayerDev &L = c->layers[k];
         GemmArgs g{};
-        g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.Wsplit16 = L.w_ih_split16; g.bias = L.bias; g.C = G;
+        g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.Wsplit16 = L.w_ih_split16; g.wscale = L.w_ih_scale; g.bias = L.bias; g.C = G;
         g.M = (int)w.M; g.N = N4; g.K = L.in; g.ldc = N4; g.B = B; g.T = T; g.act = 0; g.leaky_slope = 0.f;
         if (k == 0) { g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1; }
         else { g.A = Y[(k - 1) & 1]; g.lda = w.Wd; g.a_mode = 0; }
@@ -626,7 +629,7 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         GemmArgs g{};
         g.A = cur; g.lda = curw; g.a_mode = 0; g.W = c->lin_w[j]; g.ldw = gemm_padded_k(curw); g.bias = c->lin_b[j]; g.C = Z[j & 1];
         g.M = (int)w.M; g.N = m.lin_hidden; g.K = curw; g.ldc = m.lin_hidden; g.B = B; g.T = T;
-        g.act = 1; g.leaky_slope = m.leaky_slope; g.Wsplit16 = c->lin_w_split16[j];
+        g.act = 1; g.leaky_slope = m.leaky_slope; g.Wsplit16 = c->lin_w_split16[j]; g.wscale = c->lin_w_scale[j];
         HIPCHK(c, run_gemm(g));
         cur = Z[j & 1];
         curw = m.lin_hidden;

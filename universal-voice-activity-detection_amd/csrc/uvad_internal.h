@@ -20,7 +20,8 @@ struct GemmArgs {
     const float *W;      // [N][ldw] row-major (torch Linear / LSTM weight layout, rows possibly permuted),
                          // each row zero-padded to ldw = gemm_padded_k(K) floats
     int ldw;
-    const unsigned short *Wsplit16; // gemm_f16x3.hip only: the same matrix as two f16 planes [2][N][ldw] (low plane x 2^11)
+    const unsigned short *Wsplit16; // gemm_f16x3.hip only: w * 2^S as three f16 planes [3][N][ldw] that add up to it exactly
+    float wscale;                   // gemm_f16x3.hip only: 2^-S
     const float *bias;   // [N] or nullptr
     float *C;
     int M, N, K;
@@ -41,7 +42,7 @@ struct GemmArgs {
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t s);
 int gemm_padded_k(int K);   // K rounded up to the kernel's K-step
 hipError_t launch_gemm_f16x3(const GemmArgs &a, hipStream_t s);
-bool split_weights_f16x2(const float *w, size_t n, unsigned short *out /*[2][n]*/);   // false: a weight is outside the f16 range
+bool split_weights_f16x3(const float *w, size_t n, unsigned short *out /*[3][n]*/, float *wscale);   // false: not representable
 // *flag = 1 if any of the n values is non-finite or |x| >= limit, else 0 (one pass, async on s)
 hipError_t launch_range_flag(const float *x, size_t n, float limit, int *flag, hipStream_t s);
 
