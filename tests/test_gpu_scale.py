@@ -62,7 +62,7 @@ def test_cfg2_full_size_logit_parity(scale):
     assert pin < 1e-6
     st_cpu = ps.error_stats(ref[:n64], truth)
     print("  " + ps.fmt("CPU fp32 vs f64", st_cpu))
-    for mode in ("f16x3", "f32"):
+    for mode in ("f16p", "f32"):
         rt.set_gemm_mode(mode)
         g, _ = rt.classify(feats, want_probs=False)
         g = g.cpu().numpy()
@@ -77,7 +77,7 @@ def test_cfg2_full_size_logit_parity(scale):
             for key in ("rms", "mean", "p99.9", "max"):
                 assert st[key] <= REL * st_cpu[key], (mode, key, st[key], st_cpu[key])
             assert st["frames_over_bound"] <= REL * max(st_cpu["frames_over_bound"], 1)
-    rt.set_gemm_mode("f16x3")
+    rt.set_gemm_mode("f16p")
 
 
 def test_cfg3_feature_loop_hipgraph_4096_streams():

@@ -46,7 +46,7 @@ for scale in [float(x) for x in args.scales.split(",")]:
         st_cpu = ps.error_stats(ref, truth)
         print(f"scale x{scale:g} seed {seed} B={B}: logits {truth.min():.2f}..{truth.max():.2f}  (torch f64 {t64:.1f} s, f32 {t32:.1f} s)")
         print("  " + ps.fmt("CPU fp32 vs f64      ", st_cpu))
-        for mode in ("f16x3", "f32"):
+        for mode in ("f16p", "f32"):
             rt.set_gemm_mode(mode)
             g, _ = rt.classify(feats, want_probs=False)
             g = g.cpu().numpy()

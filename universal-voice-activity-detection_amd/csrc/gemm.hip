@@ -141,7 +141,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a, int mt, int n
         const int col = C0 + wc * 64 + (J) * 32 + fr;                                                \
         const int rbase = R0 + wr * 64 + (I) * 32 + 4 * fh;                                          \
         const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;                                \
-        float *crow = a.C + (size_t)rbase * a.ldc + col;                                             \
+        /* c_blocked: tile-blocked gate matrix (g_index); the 16 rows of a lane stay inside one 128-row tile */ \
+        float *crow = a.c_blocked ? a.C + g_index(rbase, col < a.N ? col : 0, a.N) : a.C + (size_t)rbase * a.ldc + col; \
+        const size_t cstride = a.c_blocked ? 64 : (size_t)a.ldc;                                     \
         float v[16];                                                                                 \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                             \
             v[r] = ACC[r] + bias;                                                                    \
@@ -151,11 +153,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a, int mt, int n
             _Pragma("unroll") for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(v[r]));             \
         } else if (full) {                                                                           \
             _Pragma("unroll") for (int r = 0; r < 16; ++r)                                           \
-                crow[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldc] = v[r];                               \
+                crow[(size_t)((r & 3) + 8 * (r >> 2)) * cstride] = v[r];                             \
         } else {                                                                                     \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                         \
                 const int dr = (r & 3) + 8 * (r >> 2);                                               \
-                if (rbase + dr < Rend && col < a.N) crow[(size_t)dr * a.ldc] = v[r];                  \
+                if (rbase + dr < Rend && col < a.N) crow[(size_t)dr * cstride] = v[r];                \
             }                                                                                        \
         }                                                                                            \
     }

@@ -1,0 +1,285 @@
+// gemm_f16p.hip -- f32-accurate GEMM on the f16 matrix cores, operands PRE-SPLIT into f16 planes ("f16p").
+//   C = act(A * W^T + b) for the time-parallel contractions of the classifier: the four LSTM input projections
+//   (x_t * W_ih^T + b_ih + b_hh, nn.LSTM inside PyanNet2.forward, src/models/segmentation/PyanNet2.py:169-172) and the
+//   feed-forward layers (leaky_relu(x * W^T + b), PyanNet2.py:183-185).
+//
+// Numerics
+//   Weights are static, so their representation must be EXACT: a rounded weight is not noise but a slightly different
+//   network, and the near-chaotic x4 test network turns a 2^-23 relative weight perturbation into a mean logit error as large
+//   as the whole fp32 CPU path's (measured).  Each weight matrix is scaled by a power of two (2^S, so
+//   that max|w| lands in [2^13, 2^14): no piece of a weight that matters falls into the f16 subnormals) and split on the
+//   host into THREE f16 planes that add up to the f32 value exactly (11 + 11 + 2 mantissa bits):
+//       w * 2^S = P0 + (P1 + P2) * 2^-11,   P0 = f16(ws),  P1 = f16((ws - P0) * 2^11),  P2 = f16((ws - P0) * 2^11 - P1)
+//   Activations vary, so their rounding IS noise; they arrive as TWO planes written by the kernel that produced them
+//   (the recurrent kernel's epilogue, the feature split kernel, this kernel's own epilogue):
+//       a ~= a1 + a2 * 2^-11,   a1 = f16(a), a2 = f16((a - a1) * 2^11)            (|residual| <= 2^-22 |a|, 22 of 24 bits)
+//   The product keeps four terms in two f32 accumulator sets (f16 x f16 products are exact in f32 and
+//   v_mfma_f32_32x32x16_f16 accumulates in f32):
+//       hi += a1*P0;   lo += a1*P1 + a2*P0 + a1*P2;   a*w = (hi + lo * 2^-11) * 2^-S   (dropped: a2*P1, a2*P2 <= 2^-22 relative)
+//   Operand range: |a| < 65504.  h of an LSTM is in (-1, 1); the feed-forward activations are bounded by the weights
+//   (uvad_finalize checks the bound); caller-supplied features are checked on the device (split_features_kernel sets a flag
+//   and the exact-f32 kernel of gemm.hip runs the first projection instead, GemmArgs::gate).
+//
+// gfx950 design (HBM-bound on paper: 1.05 GB of gate pre-activations written per K = 256 projection at cfg 2)
+//   * 128 x 64 output tile per 256-thread workgroup (4 waves as 2 x 2, each 64 x 32 = two 32x32 MFMA tiles x two accumulator
+//     sets = 64 accumulator registers): ~110 VGPRs, so FOUR workgroups share a CU and hide each other's barriers and
+//     memory latency -- occupancy instead of a deep software pipeline.
+//   * All five operand planes of a K-step go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+//     VALU), double buffered: one barrier per K-step, the next step's loads are in flight during this step's MFMAs.
+//   * Planes live in HBM in a K-BLOCKED layout (plane_index() in uvad_internal.h): [row tile][16-column block][row][16], so
+//     the slab a workgroup needs for one 16-deep k-block of one plane is ONE contiguous 4 KiB (A, 128 rows) / 2 KiB (W, 64
+//     rows) run and every DMA wave-instruction reads eight full 128-byte lines.  (Row-major planes were measured first:
+//     a K-step then touches 32-byte pieces of rows 512 bytes apart, 32 L2 requests per wave-instruction, and the kernel is
+//     bound by the L2 request rate -- TA busy 77 %, MFMA busy 21 %, profiles/README.md.)
+//   * The LDS image is dense (a DMA wave-instruction writes 1 KiB contiguously); bank conflicts of the ds_read_b128
+//     fragment reads are removed by an XOR swizzle of the 16-byte chunk index applied to the DMA's per-lane SOURCE
+//     address and to the read address (cdna_hip_programming.md section 5.4 rule 21).
+//   * The epilogue stores straight from the accumulators: the 32x32 C layout gives each store instruction two full 128-byte
+//     row segments (measured in round 1: staging the tile through LDS for 16-byte stores moved no time).
+//   * Block ids are remapped so that the N-tiles sharing one A row panel run on the same XCD (private L2) back to back.
+#include "uvad_internal.h"
+
+namespace uvad {
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+constexpr int BM = PLANE_TILE, BN = 64;
+#ifndef UVAD_F16P_NKB
+#define UVAD_F16P_NKB 1
+#endif
+
+// LDS image of one 16-deep k-block (f16 elements): 128 rows of A hi, 128 of A lo, 64 rows each of W P0 / P1 / P2; a row is
+// 16 elements = two 16-byte chunks, chunk c of row r sits at slot c ^ ((r >> 3) & 1) (rows r and r + 8 share a bank line)
+constexpr int KB_AHI = 0, KB_ALO = BM * 16, KB_W0 = 2 * BM * 16, KB_W1 = KB_W0 + BN * 16, KB_W2 = KB_W1 + BN * 16, KB_ELEMS = KB_W2 + BN * 16;
+
+template <int NKB, bool OUT_PLANES>   // NKB: 16-deep k-blocks per pipeline stage (1: 14 KiB stages, 2: 28 KiB)
+__global__ __launch_bounds__(256, NKB == 1 ? 4 : 2) void gemm_f16p_kernel(GemmArgs a, int mt, int nt) {
+    constexpr int STAGE = NKB * KB_ELEMS;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * STAGE];
+
+    if (a.gate && (*a.gate != 0) != (a.gate_run_if_set != 0)) return;   // device-side kernel selection (see GemmArgs)
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch, speed only)
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int m_tile = (idx / nt) * 8 + xcd, n_tile = idx % nt;
+    if (m_tile >= mt) return;
+    const int R0 = m_tile * BM, C0 = n_tile * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- DMA plan.  Per k-block: the A hi slab (256 chunks = one instruction of the whole workgroup), the A lo slab, the
+    //      W P0 slab (waves 0-1) + W P1 slab (waves 2-3), the W P2 slab (waves 0-1).  A lane always fetches the chunk that
+    //      belongs at its LDS slot (slot s of row r holds chunk s ^ ((r >> 3) & 1)): bases are wave-uniform, the lane offset
+    //      is one constant for A slabs and one for W slabs.
+    const int nkb = a.K / 16;                                   // k-blocks of the whole contraction
+    const unsigned short *a_hi = a.Ah + (size_t)m_tile * nkb * (BM * 16);
+    const unsigned short *a_lo = a.Al + (size_t)m_tile * nkb * (BM * 16);
+    const size_t wplane = (size_t)((a.N + BN - 1) / BN) * nkb * (BN * 16);   // elements per W plane (N padded to whole 64-row tiles)
+    const unsigned short *w_a = a.Wsplit16 + (wave < 2 ? 0 : wplane) + (size_t)n_tile * nkb * (BN * 16);   // P0 or P1
+    const unsigned short *w_2 = a.Wsplit16 + 2 * wplane + (size_t)n_tile * nkb * (BN * 16);
+    const int ra = tid >> 1, rw = (tid & 127) >> 1;
+    const unsigned off_a = (unsigned)((ra * 2 + ((tid & 1) ^ ((ra >> 3) & 1))) * 8);
+    const unsigned off_w = (unsigned)((rw * 2 + ((tid & 1) ^ ((rw >> 3) & 1))) * 8);
+    auto issue = [&](int stage, int kb0) {
+#pragma unroll
+        for (int b = 0; b < NKB; ++b) {
+            unsigned short *img = lds + stage * STAGE + b * KB_ELEMS;
+            const size_t ka = (size_t)(kb0 + b) * (BM * 16), kw = (size_t)(kb0 + b) * (BN * 16);
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_hi + ka + off_a), (lptr_t)(img + KB_AHI + wave * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_lo + ka + off_a), (lptr_t)(img + KB_ALO + wave * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_a + kw + off_w), (lptr_t)(img + KB_W0 + wave * 512), 16, 0, 0);   // waves 2-3 land in KB_W1
+            if (wave < 2) __builtin_amdgcn_global_load_lds((gptr_t)(w_2 + kw + off_w), (lptr_t)(img + KB_W2 + wave * 512), 16, 0, 0);
+        }
+    };
+
+    f32x16 hi0, hi1, lo0, lo1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { hi0[r] = 0.f; hi1[r] = 0.f; lo0[r] = 0.f; lo1[r] = 0.f; }
+
+    // fragment addresses (f16 elements inside a k-block image): lane = (row fr of the 32-row MFMA tile, k-half fh)
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int arow0 = wr * 64 + fr, arow1 = arow0 + 32, wrow = wc * 32 + fr;
+    const int fa0 = arow0 * 16 + ((fh ^ ((arow0 >> 3) & 1)) * 8), fa1 = arow1 * 16 + ((fh ^ ((arow1 >> 3) & 1)) * 8);
+    const int fw = wrow * 16 + ((fh ^ ((wrow >> 3) & 1)) * 8);
+
+    const int nk = nkb / NKB;   // K is padded to a multiple of 32 by the producers (zero columns)
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();   // (hipcc waits vmcnt(0) here) stage kt has landed for every wave; everyone is done reading stage kt-1
+#ifndef UVAD_F16P_ABL_NODMA   // diagnostic builds (tools/stage_times.py --lib): outputs of ablated builds are meaningless
+        if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * NKB);
+#endif
+#pragma unroll
+        for (int b = 0; b < NKB; ++b) {
+            const unsigned short *st = lds + (kt & 1) * STAGE + b * KB_ELEMS;
+            const f16x8 a0h = *reinterpret_cast<const f16x8 *>(st + KB_AHI + fa0);
+            const f16x8 a0l = *reinterpret_cast<const f16x8 *>(st + KB_ALO + fa0);
+            const f16x8 a1h = *reinterpret_cast<const f16x8 *>(st + KB_AHI + fa1);
+            const f16x8 a1l = *reinterpret_cast<const f16x8 *>(st + KB_ALO + fa1);
+            const f16x8 w0 = *reinterpret_cast<const f16x8 *>(st + KB_W0 + fw);
+            const f16x8 w1 = *reinterpret_cast<const f16x8 *>(st + KB_W1 + fw);
+            const f16x8 w2 = *reinterpret_cast<const f16x8 *>(st + KB_W2 + fw);
+#ifdef UVAD_F16P_ABL_NOMFMA
+            asm volatile("" ::"v"(a0h), "v"(a0l), "v"(a1h), "v"(a1l), "v"(w0), "v"(w1), "v"(w2));
+            continue;
+#endif
+            lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w1, lo0, 0, 0, 0);
+            lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w1, lo1, 0, 0, 0);
+            lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, w0, lo0, 0, 0, 0);
+            lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, w0, lo1, 0, 0, 0);
+            lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w2, lo0, 0, 0, 0);
+            lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w2, lo1, 0, 0, 0);
+            hi0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w0, hi0, 0, 0, 0);
+            hi1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w0, hi1, 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: (hi + lo * 2^-11) * 2^-S + bias, activation, straight from the accumulators.  C layout of the 32x32 MFMA:
+    //      register r of lane (fr, fh) = row 8*(r>>2) + 4*fh + (r&3), column fr.
+    const int col = C0 + wc * 32 + fr;
+    const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const f32x16 &HI = mi ? hi1 : hi0;
+        const f32x16 &LO = mi ? lo1 : lo0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = R0 + wr * 64 + mi * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+            float v = __builtin_fmaf(__builtin_fmaf(LO[r], 0.00048828125f, HI[r]), a.wscale, bias);
+            if (a.act == 1) v = v >= 0.f ? v : a.leaky_slope * v;
+            if constexpr (OUT_PLANES) {
+                // consumer = another f16p GEMM whose K is ldc (N rounded up to 32): its padding columns must read as zero
+                if (row < a.M && col < a.ldc) {
+                    if (col >= a.N) v = 0.f;
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)((v - (float)h) * 2048.0f);
+                    const size_t o = plane_index(row, col, a.ldc);
+                    a.Ch[o] = __builtin_bit_cast(unsigned short, h);
+                    a.Cl[o] = __builtin_bit_cast(unsigned short, l);
+                }
+            } else {
+                const size_t o = a.c_blocked ? g_index(row, col < a.N ? col : 0, a.N) : (size_t)row * a.ldc + col;
+#ifdef UVAD_F16P_ABL_NOSTORE
+                if (row < a.M && col < a.N && v == 12345.678f) a.C[o] = v;
+#else
+                if (row < a.M && col < a.N) a.C[o] = v;
+#endif
+            }
+        }
+    }
+}
+
+// Canonical f32 features [B][T][F] -> the two f16 planes (K-blocked, Fp columns) in tile-major row order (row m = (tile*T + t)*4 + j
+// holds sequence b = 4*tile + j at frame t; rows of padding sequences and the columns [F, Fp) are zero), and *flag = 1 if any
+// value is non-finite or outside the f16 range (the caller then runs the exact-f32 projection, see GemmArgs::gate).
+__global__ __launch_bounds__(256) void split_features_kernel(const float *x, int B, int T, int F, int Fp, int tiles, unsigned short *xh,
+                                                             unsigned short *xl, int *flag) {
+    const int q4 = Fp / 4;
+    const long long n = (long long)tiles * T * SEQ_TILE * q4;
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / q4;
+        const int c = (int)(i - m * q4) * 4;
+        const long long per_tile = (long long)T * SEQ_TILE;
+        const int tile = (int)(m / per_tile);
+        const int rem = (int)(m - (long long)tile * per_tile);
+        const int t = rem / SEQ_TILE, b = tile * SEQ_TILE + (rem - t * SEQ_TILE);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < B && c < F) v = *reinterpret_cast<const float4 *>(x + ((size_t)b * T + t) * F + c);   // F % 4 == 0
+        bad |= !(__builtin_fabsf(v.x) < 65504.0f) | !(__builtin_fabsf(v.y) < 65504.0f) | !(__builtin_fabsf(v.z) < 65504.0f) | !(__builtin_fabsf(v.w) < 65504.0f);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        unsigned short h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const _Float16 hh = (_Float16)e[k];
+            const _Float16 ll = (_Float16)((e[k] - (float)hh) * 2048.0f);
+            h[k] = __builtin_bit_cast(unsigned short, hh);
+            l[k] = __builtin_bit_cast(unsigned short, ll);
+        }
+        const size_t o = plane_index(m, c, Fp);   // c % 4 == 0: the four columns stay inside one 16-column block
+        *reinterpret_cast<uint2 *>(xh + o) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+        *reinterpret_cast<uint2 *>(xl + o) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+    }
+    if (flag && __builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+}  // namespace
+
+int gemm_f16p_padded_k(int K) { return (K + 31) / 32 * 32; }
+
+// host: f32 [N][ldw] (rows zero-padded to ldw, a multiple of 32) -> three f16 planes of w * 2^S that add up to it EXACTLY (see the
+// header), each in the K-blocked layout with 64-row tiles (N padded to whole tiles with zero rows): out holds
+// 3 * weight_plane_elems(N, ldw) elements; *wscale = 2^-S.  false: a weight is non-finite (the matrix cannot be represented).
+size_t weight_plane_elems(int N, int ldw) { return (size_t)((N + BN - 1) / BN) * BN * ldw; }
+
+bool split_weights_f16x3(const float *w, int N, int ldw, unsigned short *out, float *wscale) {
+    const size_t n = (size_t)N * ldw, pe = weight_plane_elems(N, ldw);
+    float amax = 0.0f;
+    bool finite = true;
+    for (size_t i = 0; i < n; ++i) {
+        const float a = __builtin_fabsf(w[i]);
+        if (!(a <= 3.0e38f)) finite = false;
+        if (a > amax) amax = a;
+    }
+    int S = 0;
+    if (finite && amax > 0.0f) {
+        int e;
+        (void)__builtin_frexpf(amax, &e);   // amax = m * 2^e, m in [0.5, 1)
+        S = 14 - e;                           // amax * 2^S in [2^13, 2^14)
+        if (S > 100) S = 100;
+        if (S < -100) S = -100;
+    }
+    const float up = __builtin_ldexpf(1.0f, S);
+    *wscale = __builtin_ldexpf(1.0f, -S);
+    for (size_t i = 0; i < 3 * pe; ++i) out[i] = 0;
+    const int nkb = ldw / 16;
+    for (int r = 0; r < N; ++r)
+        for (int k = 0; k < ldw; ++k) {
+            const float ws = finite ? w[(size_t)r * ldw + k] * up : 0.0f;   // exact (power of two)
+            const _Float16 p0 = (_Float16)ws;
+            const float t2 = (ws - (float)p0) * 2048.0f;            // exact
+            const _Float16 p1 = (_Float16)t2;
+            const float r2 = t2 - (float)p1;                        // exact; at most 24 - 22 significant bits are left
+            const _Float16 p2 = (_Float16)r2;
+            const size_t o = ((size_t)(r / BN) * nkb + k / 16) * (BN * 16) + (size_t)(r % BN) * 16 + k % 16;
+            __builtin_memcpy(&out[o], &p0, 2);
+            __builtin_memcpy(&out[pe + o], &p1, 2);
+            __builtin_memcpy(&out[2 * pe + o], &p2, 2);
+        }
+    return finite;
+}
+
+hipError_t launch_gemm_f16p(const GemmArgs &a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return hipSuccess;
+    if (!a.Ah || !a.Al || !a.Wsplit16 || a.K <= 0 || (a.K & 31) || a.ldw != a.K) return hipErrorInvalidValue;
+    if (a.out_planes ? (!a.Ch || !a.Cl) : !a.C) return hipErrorInvalidValue;
+    const int mt = (a.M + BM - 1) / BM, nt = ((a.out_planes ? a.ldc : a.N) + BN - 1) / BN;
+    const int grid = ((mt + 7) / 8) * 8 * nt;
+    if (a.out_planes)
+        hipLaunchKernelGGL((gemm_f16p_kernel<UVAD_F16P_NKB, true>), dim3(grid), dim3(256), 0, s, a, mt, nt);
+    else
+        hipLaunchKernelGGL((gemm_f16p_kernel<UVAD_F16P_NKB, false>), dim3(grid), dim3(256), 0, s, a, mt, nt);
+    return hipGetLastError();
+}
+
+hipError_t launch_split_features(const float *x, int B, int T, int F, int Fp, int tiles, unsigned short *xh, unsigned short *xl, int *flag,
+                                 hipStream_t s) {
+    if (flag) {
+        hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+        if (e != hipSuccess) return e;
+    }
+    const long long n = (long long)tiles * T * SEQ_TILE * (Fp / 4);
+    if (n <= 0) return hipSuccess;
+    const long long want = (n + 255) / 256;
+    const int grid = (int)(want > 4096 ? 4096 : want);
+    hipLaunchKernelGGL(split_features_kernel, dim3(grid), dim3(256), 0, s, x, B, T, F, Fp, tiles, xh, xl, flag);
+    return hipGetLastError();
+}
+
+}  // namespace uvad

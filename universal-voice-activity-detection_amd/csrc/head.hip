@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void classifier_kernel(ClsArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void untile_kernel(const float *src, int ld, int W, float *dst, int tiles, int T, int B) {
+// src_lo == nullptr: src is f32; else src / src_lo are the two f16 planes (value = hi + lo * 2^-11)
+__global__ __launch_bounds__(256) void untile_kernel(const void *src, const void *src_lo, int ld, int W, float *dst, int tiles, int T, int B) {
     const long long n4 = (long long)B * T * (W / 4);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         const int q = (int)(i % (W / 4));
@@ -63,12 +64,17 @@ __global__ __launch_bounds__(256) void untile_kernel(const float *src, int ld, i
         const int t = (int)(bt % T), b = (int)(bt / T);
         const int tile = b / SEQ_TILE, j = b - tile * SEQ_TILE;
         const size_t m = ((size_t)tile * T + t) * SEQ_TILE + j;
-        reinterpret_cast<float4 *>(dst)[i] = *reinterpret_cast<const float4 *>(src + m * ld + q * 4);
+        if (!src_lo) {
+            reinterpret_cast<float4 *>(dst)[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(src) + m * ld + q * 4);
+        } else {
+            const size_t o = plane_index(m, q * 4, ld);   // K-blocked planes: 4 consecutive columns stay inside one 16-column block
+            const _Float16 *h = reinterpret_cast<const _Float16 *>(src) + o, *l = reinterpret_cast<const _Float16 *>(src_lo) + o;
+            reinterpret_cast<float4 *>(dst)[i] = make_float4(__builtin_fmaf((float)l[0], 0.00048828125f, (float)h[0]), __builtin_fmaf((float)l[1], 0.00048828125f, (float)h[1]),
+                                                             __builtin_fmaf((float)l[2], 0.00048828125f, (float)h[2]), __builtin_fmaf((float)l[3], 0.00048828125f, (float)h[3]));
+        }
     }
 }
 
-// One thread per output frame; the window count is re-summed (kernel <= 49 taps of L1/L2-resident
-// data: 0.2 kB per thread), which keeps the kernel branch-free and exactly scipy's zero padding.
 __global__ __launch_bounds__(256) void median_kernel(const float *probs, int B, int T, int half, uint8_t *labels) {
     const long long n = (long long)B * T;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -148,18 +154,6 @@ __global__ __launch_bounds__(256) void runs_kernel(const uint8_t *labels, int B,
     }
 }
 
-// *flag |= 1 when a value is non-finite or |x| >= limit (flag zeroed by the launcher's memset node)
-__global__ __launch_bounds__(256) void range_flag_kernel(const float *x, size_t n, float limit, int *flag) {
-    bool bad = false;
-    const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const float4 v = reinterpret_cast<const float4 *>(x)[i];
-        bad |= !(__builtin_fabsf(v.x) < limit) | !(__builtin_fabsf(v.y) < limit) | !(__builtin_fabsf(v.z) < limit) | !(__builtin_fabsf(v.w) < limit);
-    }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= !(__builtin_fabsf(x[n4 * 4 + threadIdx.x]) < limit);   // NaN compares false
-    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
-}
-
 // busy-waits `ticks` of the constant 100 MHz counter (s_memrealtime), one wave: the stream-overlap probe's "long" kernel
 __global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks, unsigned long long *sink) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -175,16 +169,6 @@ __global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks, unsi
 
 hipError_t launch_spin(unsigned long long ticks, unsigned long long *sink, hipStream_t s) {
     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, ticks, sink);
-    return hipGetLastError();
-}
-
-hipError_t launch_range_flag(const float *x, size_t n, float limit, int *flag, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
-    if (e != hipSuccess) return e;
-    if (n == 0) return hipSuccess;
-    const size_t want = (n / 4 + 255) / 256;
-    const int grid = (int)(want < 1 ? 1 : want > 2048 ? 2048 : want);
-    hipLaunchKernelGGL(range_flag_kernel, dim3(grid), dim3(256), 0, s, x, n, limit, flag);
     return hipGetLastError();
 }
 
@@ -208,12 +192,12 @@ hipError_t launch_classifier(const ClsArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_untile(const float *src, int ld, int W, float *dst, int tiles, int T, int B, hipStream_t s) {
+hipError_t launch_untile(const void *src, const void *src_lo, int ld, int W, float *dst, int tiles, int T, int B, hipStream_t s) {
     const long long n4 = (long long)B * T * (W / 4);
     if (n4 <= 0) return hipSuccess;
     long long g = (n4 + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(untile_kernel, dim3((int)g), dim3(256), 0, s, src, ld, W, dst, tiles, T, B);
+    hipLaunchKernelGGL(untile_kernel, dim3((int)g), dim3(256), 0, s, src, src_lo, ld, W, dst, tiles, T, B);
     return hipGetLastError();
 }
 

@@ -91,7 +91,16 @@ __device__ __forceinline__ void gq_load(f32x4 &dst, const float *p) {
 #define UVAD_YSTORE(ptr, v) (*(ptr) = (v))
 #endif
 
-template <int H, int WAVES>
+// h_t -> the two f16 planes the next layer's f16p GEMM reads (gemm_f16p.hip: a ~= hi + lo * 2^-11; |h| < 1, so both pieces are
+// far inside the f16 range)
+__device__ __forceinline__ void store_planes(unsigned short *ph, unsigned short *pl, float h) {
+    const _Float16 hh = (_Float16)h;
+    const _Float16 hl = (_Float16)((h - (float)hh) * 2048.0f);
+    *ph = __builtin_bit_cast(unsigned short, hh);
+    *pl = __builtin_bit_cast(unsigned short, hl);
+}
+
+template <int H, int WAVES, bool PLANES>
 __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
     constexpr int HS = H + 4;   // LDS row stride (floats): the 4 sequence rows land on disjoint banks
     constexpr int PD = UVAD_LSTM_PD;
@@ -101,7 +110,8 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
 
     const int tile = blockIdx.x, dir = blockIdx.y;
     const bool reverse = dir == 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int jb = lane & 3;    // sequence within the tile (B / D operand column), gate index of the A operand
     const int blk = lane >> 2;  // MFMA block = hidden unit within the wave's row block
 
@@ -125,17 +135,30 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
     hbuf[0][jb][unit] = a.h0 ? a.h0[so] : 0.0f;
     __syncthreads();
 
-    // row of (t, jb) in the tile-major activation matrices
-    const size_t row0 = (size_t)tile * a.T * SEQ_TILE + jb;
-    const float *gbase = a.G + (size_t)dir * 4 * H + unit * 4;
-    float *ybase = a.Y + (size_t)dir * H + unit;
+    // Row of (t, jb) in the tile-major activation matrices = rowu + 4*t + jb, rowu wave-uniform.  The blocked layouts
+    // (g_index / plane_index) split into a wave-uniform part that changes with t (scalar unit) and a per-lane constant:
+    //   G: the wave's 16 units x 4 gates are exactly one 64-column tile, the 4 sequence rows adjacent -> 1 KiB contiguous per step
+    //   Y planes: the wave's 16 units are exactly one 16-column block, 4 rows adjacent -> 128 contiguous bytes per plane and step
+    const size_t rowu = (size_t)tile * a.T * SEQ_TILE;
+    const size_t row0 = rowu + jb;
+    const size_t g_wave = (size_t)(dir * (4 * H / 64) + wave) * (128 * 64);
+    const unsigned g_lane = (unsigned)(jb * 64 + blk * 4);
+    const size_t g_tile = (size_t)(a.ldg / 64) * (128 * 64);          // floats per 128-row tile of G
+    auto g_ptr = [&](int t) {
+        const size_t R = rowu + (size_t)t * SEQ_TILE;
+        return a.G + (R >> 7) * g_tile + g_wave + (R & 127) * 64 + g_lane;
+    };
+    const size_t ycol = (size_t)dir * H + unit;
+    const size_t y_wave = (size_t)(dir * (H / 16) + wave) * (PLANE_TILE * 16);
+    const unsigned y_lane = (unsigned)(jb * 16 + blk);
+    const size_t y_tile = (size_t)(a.ldy / 16) * (PLANE_TILE * 16);   // elements per 128-row tile of a Y plane
 
     f32x4 gq[PD];
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
         const int sp = p < a.T ? p : a.T - 1;
         const int t = reverse ? a.T - 1 - sp : sp;
-        gq_load(gq[p], gbase + (row0 + (size_t)t * SEQ_TILE) * a.ldg);
+        gq_load(gq[p], g_ptr(t));
     }
 
     float hlast = 0.0f;
@@ -207,7 +230,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
                 // redundant re-load of the last row is harmless)
                 const int sp = s + PD < a.T ? s + PD : a.T - 1;
                 const int tp = reverse ? a.T - 1 - sp : sp;
-                gq_load(gq[u], gbase + (row0 + (size_t)tp * SEQ_TILE) * a.ldg);
+                gq_load(gq[u], g_ptr(tp));
             }
         }
         // keep HR LDS reads in flight: [HR reads] then [4 MFMA + 1 read] per group (without this the
@@ -222,7 +245,16 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
         UVAD_STAMP_AT(0)   // [0] = h reads + MFMA chains
         hlast = lstm_cell((a0 + a1) + (a2 + a3), c);
         hbuf[(s + 1) & 1][jb][unit] = hlast;
-        UVAD_YSTORE(&ybase[(row0 + (size_t)t * SEQ_TILE) * a.ldy], hlast);
+        if constexpr (PLANES) {
+            // K-blocked plane (uvad_internal.h plane_index): the 4 sequence rows x 16 units of a wave are 128 contiguous bytes
+#ifndef UVAD_ABL_NOGMEM
+            const size_t R = rowu + (size_t)t * SEQ_TILE;
+            const size_t yo = (R >> 7) * y_tile + y_wave + (R & 127) * 16 + y_lane;
+            store_planes(a.Yh + yo, a.Yl + yo, hlast);
+#endif
+        } else {
+            UVAD_YSTORE(a.Y + (row0 + (size_t)t * SEQ_TILE) * a.ldy + ycol, hlast);
+        }
         UVAD_STAMP_AT(1)   // [1] = cell update + h write/store
 #ifndef UVAD_ABL_NOSYNC
         __syncthreads();
@@ -258,7 +290,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
 // 8 waves x (4 row blocks x 32 k-steps) = 1024 MFMAs of 32 cycles per step and workgroup; W_hh stays in 128
 // AGPRs per lane.  Rows keep the SEQ_TILE = 4 layout (a workgroup owns 4 consecutive tiles), so GEMMs and
 // the classifier are unchanged.  No state carry / chunking (the callers that need those run small batches).
-template <int H>
+template <int H, bool PLANES>
 __global__ __launch_bounds__(512) void lstm_rec16_kernel(LstmArgs a) {
     static_assert(H == 128, "written for H = 128");
     constexpr int NS = 16, RB = 4, KS = H / 4, HSK = 36, PD16 = 2;
@@ -286,8 +318,8 @@ __global__ __launch_bounds__(512) void lstm_rec16_kernel(LstmArgs a) {
     const int t4c = live ? t4 : a.tiles - 1;
     const size_t row0 = (size_t)t4c * a.T * SEQ_TILE + (j & 3);
     const int ubase = wave * 16 + q;   // unit of row block rb: ubase + 4*rb
-    const float *gbase = a.G + (size_t)dir * 4 * H + (size_t)ubase * 4;
-    float *ybase = a.Y + (size_t)dir * H + ubase;
+    const int gcol = dir * 4 * H + ubase * 4;   // G is tile-blocked (g_index); row block rb is 16 columns further
+    const size_t ycol = (size_t)dir * H + ubase;
 
     float c[RB];
 #pragma unroll
@@ -305,7 +337,7 @@ __global__ __launch_bounds__(512) void lstm_rec16_kernel(LstmArgs a) {
         const int t = reverse ? a.T - 1 - sp : sp;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
-            gq[p][rb] = *reinterpret_cast<const f32x4 *>(gbase + (row0 + (size_t)t * SEQ_TILE) * a.ldg + 16 * rb);
+            gq[p][rb] = *reinterpret_cast<const f32x4 *>(a.G + g_index(row0 + (size_t)t * SEQ_TILE, gcol + 16 * rb, a.ldg));
     }
 
     for (int s0 = 0; s0 < a.T; s0 += PD16) {
@@ -331,7 +363,7 @@ __global__ __launch_bounds__(512) void lstm_rec16_kernel(LstmArgs a) {
             const int tp = reverse ? a.T - 1 - sp : sp;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
-                gq[u2][rb] = *reinterpret_cast<const f32x4 *>(gbase + (row0 + (size_t)tp * SEQ_TILE) * a.ldg + 16 * rb);
+                gq[u2][rb] = *reinterpret_cast<const f32x4 *>(a.G + g_index(row0 + (size_t)tp * SEQ_TILE, gcol + 16 * rb, a.ldg));
         }
 #pragma unroll
         for (int i = 0; i < KS / 4; ++i) {
@@ -344,13 +376,20 @@ __global__ __launch_bounds__(512) void lstm_rec16_kernel(LstmArgs a) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[rb * KS + 4 * i + 3], hv[i].w, acc[rb], 0, 0, 0);
         }
-        float *yrow = ybase + (row0 + (size_t)t * SEQ_TILE) * a.ldy;
+        const size_t yrow = row0 + (size_t)t * SEQ_TILE;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const float h = lstm_cell(acc[rb], c[rb]);
             const int u = ubase + 4 * rb;
             hbuf[(s + 1) & 1][u >> 5][j][u & 31] = h;
-            if (live) yrow[4 * rb] = h;
+            if (live) {
+                if constexpr (PLANES) {
+                    const size_t yo = plane_index(yrow, (int)ycol + 4 * rb, a.ldy);
+                    store_planes(a.Yh + yo, a.Yl + yo, h);
+                } else {
+                    a.Y[yrow * a.ldy + ycol + 4 * rb] = h;
+                }
+            }
         }
         __syncthreads();
       }
@@ -397,17 +436,25 @@ hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
     if (a.tiles <= 0 || a.T <= 0) return hipSuccess;
     const bool can16 = a.H == 128 && a.Whh_packed16 && !a.h0 && !a.hN;
     if (a.tile_mode == 16 && !can16) return hipErrorInvalidValue;
+    const bool planes = a.Y == nullptr;
+    if (planes && (!a.Yh || !a.Yl)) return hipErrorInvalidValue;
     if (can16 && (a.tile_mode == 16 || (a.tile_mode == 0 && a.tiles * a.dirs >= 512))) {
         if (tile_used) *tile_used = 16;
-        hipLaunchKernelGGL(lstm_rec16_kernel<128>, dim3((a.tiles + 3) / 4, a.dirs), dim3(512), 0, s, a);
+        const dim3 grid16((a.tiles + 3) / 4, a.dirs);
+        if (planes) hipLaunchKernelGGL((lstm_rec16_kernel<128, true>), grid16, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((lstm_rec16_kernel<128, false>), grid16, dim3(512), 0, s, a);
         return hipGetLastError();
     }
     if (tile_used) *tile_used = 4;
     const dim3 grid(a.tiles, a.dirs);
-    if (a.H == 128)
-        hipLaunchKernelGGL((lstm_rec_kernel<128, 8>), grid, dim3(512), 0, s, a);
+    if (a.H == 128 && planes)
+        hipLaunchKernelGGL((lstm_rec_kernel<128, 8, true>), grid, dim3(512), 0, s, a);
+    else if (a.H == 128)
+        hipLaunchKernelGGL((lstm_rec_kernel<128, 8, false>), grid, dim3(512), 0, s, a);
+    else if (a.H == 64 && planes)
+        hipLaunchKernelGGL((lstm_rec_kernel<64, 4, true>), grid, dim3(256), 0, s, a);
     else if (a.H == 64)
-        hipLaunchKernelGGL((lstm_rec_kernel<64, 4>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((lstm_rec_kernel<64, 4, false>), grid, dim3(256), 0, s, a);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

@@ -22,7 +22,7 @@ struct HostTensor {
 
 struct LayerDev {
     float *w_ih = nullptr;   // [dirs*4H (permuted: dir, unit, gate)][in]
-    unsigned short *w_ih_split16 = nullptr; // the same, scaled by a power of two, as three exact f16 planes (gemm_f16x3.hip)
+    unsigned short *w_ih_split16 = nullptr; // the same, scaled by a power of two, as three exact f16 planes (gemm_f16p.hip)
     float w_ih_scale = 1.0f;
     float *bias = nullptr;   // [dirs*4H] b_ih + b_hh, same permutation
     float *w_hh = nullptr;   // [dirs][packed register image]
@@ -50,7 +50,7 @@ struct uvad_ctx {
     std::vector<unsigned short *> lin_w_split16;
     std::vector<float> lin_w_scale;
     bool f16_ok = true;   // every GEMM operand the weights determine fits the f16 range (gemm mode 1 is usable)
-    int gemm_mode = 1;    // 0: exact f32 MFMA (gemm.hip); 1: split-f16 x3 (gemm_f16x3.hip)
+    int gemm_mode = 1;    // 0: exact f32 MFMA (gemm.hip); 1: split-f16 x3 (gemm_f16p.hip)
     int rec_tile_mode = 0, rec_tile_used = 0;   // sequences per recurrent workgroup: requested (0 = by batch size) / last launched
     float *cls_w = nullptr, *cls_b = nullptr;
     // SincNet front end (sincnet.hip)
@@ -97,10 +97,11 @@ int dev_upload(uvad_ctx *c, const T *host, size_t n, T **out, bool weight = fals
 
 // Workspace carving for B sequences of T frames (all offsets in bytes, 256-B aligned).
 struct WsLayout {
-    int tiles = 0, D = 0, Wd = 0;
+    int tiles = 0, D = 0, Wd = 0, Fp = 0, Zw = 0;
     size_t M = 0;
-    size_t off_G = 0, off_Y[2] = {0, 0}, off_Z[2] = {0, 0}, off_feats = 0, off_flag = 0, total = 0;
+    size_t off_G = 0, off_Y[2] = {0, 0}, off_Z[2] = {0, 0}, off_feats = 0, off_fplanes = 0, off_flag = 0, total = 0;
 };
+// Activation buffers hold EITHER f32 rows OR two f16 planes of the same row width (hi plane, then the lo plane): same bytes.
 WsLayout carve(const uvad_ctx *c, int B, int64_t T) {
     WsLayout w;
     const uvad_model_cfg &m = c->mc;
@@ -108,11 +109,15 @@ WsLayout carve(const uvad_ctx *c, int B, int64_t T) {
     w.D = m.bidirectional ? 2 : 1;
     w.Wd = m.hidden * w.D;
     w.M = (size_t)w.tiles * SEQ_TILE * (size_t)T;
+    w.Fp = gemm_f16p_padded_k(m.in_dim);
+    w.Zw = m.lin_layers > 0 ? gemm_f16p_padded_k(m.lin_hidden) : 0;
     size_t o = 0;
-    w.off_G = o; o += align_up(w.M * 4 * m.hidden * w.D * sizeof(float));
-    for (int i = 0; i < 2; ++i) { w.off_Y[i] = o; o += align_up(w.M * w.Wd * sizeof(float)); }
-    for (int i = 0; i < 2; ++i) { w.off_Z[i] = o; o += align_up(w.M * (size_t)(m.lin_layers > 0 ? m.lin_hidden : 0) * sizeof(float)); }
+    w.off_G = o; o += align_up(plane_rows(w.M) * 4 * m.hidden * w.D * sizeof(float));   // tile-blocked: whole 128-row tiles
+    const size_t Mp = plane_rows(w.M);   // K-blocked planes come in whole 128-row tiles
+    for (int i = 0; i < 2; ++i) { w.off_Y[i] = o; o += align_up(Mp * w.Wd * sizeof(float)); }
+    for (int i = 0; i < 2; ++i) { w.off_Z[i] = o; o += align_up(Mp * (size_t)w.Zw * sizeof(float)); }
     w.off_feats = o; o += align_up((size_t)B * T * (size_t)(c->has_fb && c->fb.n_mels > m.in_dim ? c->fb.n_mels : m.in_dim) * sizeof(float));
+    w.off_fplanes = o; o += align_up(Mp * (size_t)w.Fp * sizeof(float));   // f16 planes of the features (split-f16 GEMM mode)
     w.off_flag = o; o += align_up(sizeof(int));   // device-side "features outside the f16 range" flag (uvad_classify)
     w.total = o;
     return w;
@@ -347,8 +352,8 @@ int uvad_finalize(uvad_ctx *c) {
         int r;
         if ((r = dev_upload(c, wp.data(), wp.size(), &L.w_ih, true))) return r;
         {
-            std::vector<unsigned short> sp(3 * wp.size());
-            if (!split_weights_f16x3(wp.data(), wp.size(), sp.data(), &L.w_ih_scale)) c->f16_ok = false;
+            std::vector<unsigned short> sp(3 * weight_plane_elems(D * 4 * H, inp));
+            if (!split_weights_f16x3(wp.data(), D * 4 * H, inp, sp.data(), &L.w_ih_scale)) c->f16_ok = false;
             if ((r = dev_upload(c, sp.data(), sp.size(), &L.w_ih_split16, true))) return r;
         }
         if ((r = dev_upload(c, bp.data(), bp.size(), &L.bias, true))) return r;
@@ -381,8 +386,8 @@ int uvad_finalize(uvad_ctx *c) {
         }
         if ((r = dev_upload(c, wpad.data(), wpad.size(), &c->lin_w[j], true))) return r;
         {
-            std::vector<unsigned short> sp(3 * wpad.size());
-            if (!split_weights_f16x3(wpad.data(), wpad.size(), sp.data(), &c->lin_w_scale[j])) c->f16_ok = false;
+            std::vector<unsigned short> sp(3 * weight_plane_elems(m.lin_hidden, prevp));
+            if (!split_weights_f16x3(wpad.data(), m.lin_hidden, prevp, sp.data(), &c->lin_w_scale[j])) c->f16_ok = false;
             if ((r = dev_upload(c, sp.data(), sp.size(), &c->lin_w_split16[j], true))) return r;
         }
         if ((r = dev_upload(c, b->data.data(), b->data.size(), &c->lin_b[j], true))) return r;
@@ -584,36 +589,51 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
     if (ws_bytes < w.total) return fail(c, UVAD_E_WORKSPACE, "workspace too small: need " + std::to_string(w.total) + " bytes");
     if (w.M > (size_t)0x7fffffff) return fail(c, UVAD_E_UNSUPPORTED, "B*T exceeds 2^31 rows; split the batch");
     char *base = reinterpret_cast<char *>(ws);
-    float *Y[2] = {reinterpret_cast<float *>(base + w.off_Y[0]), reinterpret_cast<float *>(base + w.off_Y[1])};
-    float *Z[2] = {reinterpret_cast<float *>(base + w.off_Z[0]), reinterpret_cast<float *>(base + w.off_Z[1])};
     float *G = reinterpret_cast<float *>(base + w.off_G);
     int *flag = reinterpret_cast<int *>(base + w.off_flag);
     const int H = m.hidden, D = w.D, N4 = 4 * H * D;
+    // Activation buffer i as f32 rows, or as the (hi, lo) f16 planes of `width` columns
+    auto Yf = [&](int i) { return reinterpret_cast<float *>(base + w.off_Y[i]); };
+    auto Zf = [&](int i) { return reinterpret_cast<float *>(base + w.off_Z[i]); };
+    auto hi_of = [&](size_t off) { return reinterpret_cast<unsigned short *>(base + off); };
+    auto lo_of = [&](size_t off, int width) { return reinterpret_cast<unsigned short *>(base + off) + plane_rows(w.M) * (size_t)width; };
     // the split-f16 GEMM needs operands inside the f16 range: weights were checked by uvad_finalize (f16_ok)
     const bool f16 = c->gemm_mode == 1 && c->f16_ok;
-    auto run_gemm = [&](const GemmArgs &g) { return f16 ? launch_gemm_f16x3(g, s) : launch_gemm(g, s); };
+    // the last LSTM layer feeds the classifier kernel directly when there are no feed-forward layers: f32 then
+    auto y_planes = [&](int k) { return f16 && (k + 1 < m.num_layers || m.lin_layers > 0); };
     if (c->timing && record_start) HIPCHK(c, hipEventRecord(c->ev[0], s));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     for (int k = 0; k < m.num_layers; ++k) {
         const LayerDev &L = c->layers[k];
         GemmArgs g{};
         g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.Wsplit16 = L.w_ih_split16; g.wscale = L.w_ih_scale; g.bias = L.bias; g.C = G;
-        g.M = (int)w.M; g.N = N4; g.K = L.in; g.ldc = N4; g.B = B; g.T = T; g.act = 0; g.leaky_slope = 0.f;
-        if (k == 0) { g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1; }
-        else { g.A = Y[(k - 1) & 1]; g.lda = w.Wd; g.a_mode = 0; }
+        g.M = (int)w.M; g.N = N4; g.ldc = N4; g.c_blocked = 1; g.B = B; g.T = T; g.act = 0; g.leaky_slope = 0.f;
         if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k], s));
-        if (k == 0 && f16 && check_range) {
-            HIPCHK(c, launch_range_flag(d_feats, (size_t)B * T * m.in_dim, 65504.0f, flag, s));
-            g.gate = flag; g.gate_run_if_set = 0;
-            HIPCHK(c, launch_gemm_f16x3(g, s));
-            g.gate_run_if_set = 1;
-            HIPCHK(c, launch_gemm(g, s));
+        if (f16) {
+            if (k == 0) {
+                HIPCHK(c, launch_split_features(d_feats, B, T, m.in_dim, w.Fp, w.tiles, hi_of(w.off_fplanes), lo_of(w.off_fplanes, w.Fp),
+                                                check_range ? flag : nullptr, s));
+                g.Ah = hi_of(w.off_fplanes); g.Al = lo_of(w.off_fplanes, w.Fp); g.lda = w.Fp; g.K = w.Fp;
+                if (check_range) { g.gate = flag; g.gate_run_if_set = 0; }
+            } else {
+                g.Ah = hi_of(w.off_Y[(k - 1) & 1]); g.Al = lo_of(w.off_Y[(k - 1) & 1], w.Wd); g.lda = w.Wd; g.K = w.Wd;
+            }
+            HIPCHK(c, launch_gemm_f16p(g, s));
+            if (k == 0 && check_range) {   // the same projection by the exact kernel, run only if the flag is set
+                g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1; g.K = L.in; g.gate_run_if_set = 1;
+                HIPCHK(c, launch_gemm(g, s));
+            }
         } else {
-            HIPCHK(c, run_gemm(g));
+            g.K = L.in;
+            if (k == 0) { g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1; }
+            else { g.A = Yf((k - 1) & 1); g.lda = w.Wd; g.a_mode = 0; }
+            HIPCHK(c, launch_gemm(g, s));
         }
         if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k + 1], s));
         LstmArgs r{};
-        r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.Whh_packed16 = L.w_hh16; r.Y = Y[k & 1]; r.ldy = w.Wd;
+        r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.Whh_packed16 = L.w_hh16; r.ldy = w.Wd;
+        if (y_planes(k)) { r.Yh = hi_of(w.off_Y[k & 1]); r.Yl = lo_of(w.off_Y[k & 1], w.Wd); }
+        else r.Y = Yf(k & 1);
         r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D; r.tile_mode = ss ? 4 : c->rec_tile_mode;
         if (ss) {   // carried (h, c) of this layer, updated in place
             r.h0 = r.hN = ss->h + (size_t)k * ss->layer_stride;
@@ -623,15 +643,25 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
     }
     if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * m.num_layers], s));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
-    const float *cur = Y[(m.num_layers - 1) & 1];
+    const int last = (m.num_layers - 1) & 1;
+    const float *cur = Yf(last);
     int curw = w.Wd;
     for (int j = 0; j < m.lin_layers; ++j) {
         GemmArgs g{};
-        g.A = cur; g.lda = curw; g.a_mode = 0; g.W = c->lin_w[j]; g.ldw = gemm_padded_k(curw); g.bias = c->lin_b[j]; g.C = Z[j & 1];
-        g.M = (int)w.M; g.N = m.lin_hidden; g.K = curw; g.ldc = m.lin_hidden; g.B = B; g.T = T;
-        g.act = 1; g.leaky_slope = m.leaky_slope; g.Wsplit16 = c->lin_w_split16[j]; g.wscale = c->lin_w_scale[j];
-        HIPCHK(c, run_gemm(g));
-        cur = Z[j & 1];
+        g.W = c->lin_w[j]; g.ldw = gemm_padded_k(curw); g.Wsplit16 = c->lin_w_split16[j]; g.wscale = c->lin_w_scale[j]; g.bias = c->lin_b[j];
+        g.M = (int)w.M; g.N = m.lin_hidden; g.B = B; g.T = T; g.act = 1; g.leaky_slope = m.leaky_slope;
+        if (f16) {
+            const size_t in_off = j == 0 ? w.off_Y[last] : w.off_Z[(j - 1) & 1];
+            const int in_w = j == 0 ? w.Wd : w.Zw;
+            g.Ah = hi_of(in_off); g.Al = lo_of(in_off, in_w); g.lda = in_w; g.K = in_w;
+            if (j + 1 < m.lin_layers) { g.out_planes = 1; g.Ch = hi_of(w.off_Z[j & 1]); g.Cl = lo_of(w.off_Z[j & 1], w.Zw); g.ldc = w.Zw; }
+            else { g.C = Zf(j & 1); g.ldc = m.lin_hidden; }
+            HIPCHK(c, launch_gemm_f16p(g, s));
+        } else {
+            g.A = cur; g.lda = curw; g.a_mode = 0; g.K = curw; g.C = Zf(j & 1); g.ldc = m.lin_hidden;
+            HIPCHK(c, launch_gemm(g, s));
+        }
+        cur = Zf(j & 1);
         curw = m.lin_hidden;
     }
     ClsArgs q{};
@@ -682,13 +712,15 @@ int uvad_get_taps(uvad_ctx *c, int B, int T, float *d_lstm_out, float *d_lin_out
     const WsLayout w = carve(c, B, T);
     const char *base = reinterpret_cast<const char *>(ws);
     if (d_lstm_out) {
-        const float *y = reinterpret_cast<const float *>(base + w.off_Y[(m.num_layers - 1) & 1]);
-        HIPCHK(c, launch_untile(y, w.Wd, w.Wd, d_lstm_out, w.tiles, T, B, (hipStream_t)stream));
+        const char *y = base + w.off_Y[(m.num_layers - 1) & 1];
+        const bool planes = c->gemm_mode == 1 && c->f16_ok && m.lin_layers > 0;   // what classify_impl made the last layer write
+        HIPCHK(c, launch_untile(y, planes ? y + plane_rows(w.M) * (size_t)w.Wd * sizeof(unsigned short) : nullptr, w.Wd, w.Wd, d_lstm_out, w.tiles, T, B,
+                                (hipStream_t)stream));
     }
     if (d_lin_out) {
         if (m.lin_layers <= 0) return fail(c, UVAD_E_ARG, "model has no feed-forward layers");
         const float *z = reinterpret_cast<const float *>(base + w.off_Z[(m.lin_layers - 1) & 1]);
-        HIPCHK(c, launch_untile(z, m.lin_hidden, m.lin_hidden, d_lin_out, w.tiles, T, B, (hipStream_t)stream));
+        HIPCHK(c, launch_untile(z, nullptr, m.lin_hidden, m.lin_hidden, d_lin_out, w.tiles, T, B, (hipStream_t)stream));
     }
     return UVAD_OK;
 }

@@ -11,49 +11,82 @@ namespace uvad {
 // so that the SEQ_TILE rows one recurrent workgroup needs at step t are adjacent in HBM.
 constexpr int SEQ_TILE = 4;
 
-// ---- gemm.hip / gemm_f16x3.hip -----------------------------------------------------------
+// f16 activation planes (the operands of gemm_f16p.hip) are K-BLOCKED: rows in tiles of PLANE_TILE, columns in blocks of 16,
+//   element (row, col) of a plane with `width` columns (a multiple of 16) lives at plane_index(row, col, width),
+// so the PLANE_TILE x 16 slab one GEMM workgroup needs per k-block is one contiguous 4 KiB run.  A plane of M rows
+// occupies plane_rows(M) * width elements.
+constexpr int PLANE_TILE = 128;
+__host__ __device__ inline size_t plane_index(size_t row, int col, int width) {
+    return ((row / PLANE_TILE) * (size_t)(width / 16) + (size_t)(col / 16)) * (PLANE_TILE * 16) + (row % PLANE_TILE) * 16 + (size_t)(col % 16);
+}
+inline size_t plane_rows(size_t M) { return (M + PLANE_TILE - 1) / PLANE_TILE * PLANE_TILE; }
+
+// The gate pre-activations G (output of the projection GEMMs, input of the recurrent kernels) are TILE-BLOCKED:
+// [128-row tile][64-column tile][128][64] f32, so a GEMM workgroup's 128 x 64 output tile is one contiguous 32 KiB run
+// (row-major G made every workgroup write 128 pieces of 256 bytes 4 KiB apart: measured 2.6 TB/s, not overlapped with
+// the K loops) and the 4 rows x 64 gate columns (16 units x 4 gates) a recurrent wave reads per step are one contiguous KiB.
+// ncols (= 4 * hidden * directions) is a multiple of 64; a G of M rows occupies plane_rows(M) * ncols floats.
+__host__ __device__ inline size_t g_index(size_t row, int col, int ncols) {
+    return ((row / 128) * (size_t)(ncols / 64) + (size_t)(col / 64)) * (128 * 64) + (row % 128) * 64 + (size_t)(col % 64);
+}
+
+// ---- gemm.hip / gemm_f16p.hip -------------------------------------------------------------
 // C[M][ldc] (cols [0,N)) = act( A[M][K] * W[N][K]^T + bias[N] ).
-//   gemm.hip        exact f32 on v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain);
-//   gemm_f16x3.hip  f32-accurate on the f16 matrix cores with 2-way split operands.
+//   gemm.hip       exact f32 on v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain); A and C are f32.
+//   gemm_f16p.hip  f32-accurate on the f16 matrix cores; A arrives (and C may leave) as two f16 PLANES
+//                  x ~= hi + lo * 2^-11 written by the producing kernel, W as three exact f16 planes (see gemm_f16p.hip).
 struct GemmArgs {
+    // ---- gemm.hip operands
     const float *A;      // activations
     const float *W;      // [N][ldw] row-major (torch Linear / LSTM weight layout, rows possibly permuted),
                          // each row zero-padded to ldw = gemm_padded_k(K) floats
+    // ---- gemm_f16p.hip operands
+    const unsigned short *Ah, *Al;    // K-blocked f16 planes of the activations, K columns (columns past the true width zero)
+    const unsigned short *Wsplit16;   // w * 2^S as three K-blocked f16 planes (64-row tiles) that add up to it exactly
+    float wscale;                     // 2^-S
+    unsigned short *Ch, *Cl;          // out_planes: K-blocked f16 planes of the result, ldc columns ([N, ldc) written as zero)
+    int out_planes;
+    // ---- common
+    int c_blocked;       // C is the tile-blocked gate matrix (g_index, ncols = N) instead of row-major [M][ldc]
     int ldw;
-    const unsigned short *Wsplit16; // gemm_f16x3.hip only: w * 2^S as three f16 planes [3][N][ldw] that add up to it exactly
-    float wscale;                   // gemm_f16x3.hip only: 2^-S
     const float *bias;   // [N] or nullptr
     float *C;
-    int M, N, K;
+    int M, N, K;         // gemm_f16p.hip: K = the padded width (multiple of 32)
     int lda, ldc;
     // a_mode 0: row m of A is A + m*lda.
-    // a_mode 1: A is canonical [B][T][K]; row m = (tile*T + t)*SEQ_TILE + j reads sequence
+    // a_mode 1 (gemm.hip only): A is canonical [B][T][K]; row m = (tile*T + t)*SEQ_TILE + j reads sequence
     //           b = tile*SEQ_TILE + j at frame t (zeros when b >= B).
     //           (rows of padded sequences and rows past the tile's range are clamped, never stored)
     int a_mode, B, T;
     float leaky_slope;   // act: v >= 0 ? v : slope*v when act == 1
     int act;
     // Device-side kernel selection for caller-supplied features (uvad_classify): when `gate` is set the kernel
-    // returns at once unless (*gate != 0) == gate_run_if_set.  *gate is written by launch_range_flag() earlier on
-    // the same stream, so the f16 split never sees an operand outside the f16 range and no host sync is needed.
+    // returns at once unless (*gate != 0) == gate_run_if_set.  *gate is written by launch_split_features() earlier on
+    // the same stream, so the f16 split never feeds an operand outside the f16 range to the matrix cores and no host
+    // sync is needed.
     const int *gate;
     int gate_run_if_set;
 };
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t s);
-int gemm_padded_k(int K);   // K rounded up to the kernel's K-step
-hipError_t launch_gemm_f16x3(const GemmArgs &a, hipStream_t s);
-bool split_weights_f16x3(const float *w, size_t n, unsigned short *out /*[3][n]*/, float *wscale);   // false: not representable
-// *flag = 1 if any of the n values is non-finite or |x| >= limit, else 0 (one pass, async on s)
-hipError_t launch_range_flag(const float *x, size_t n, float limit, int *flag, hipStream_t s);
+int gemm_padded_k(int K);        // gemm.hip: K rounded up to its K-step (weight row padding)
+hipError_t launch_gemm_f16p(const GemmArgs &a, hipStream_t s);
+int gemm_f16p_padded_k(int K);   // gemm_f16p.hip: plane row width for a true width K (multiple of 32)
+size_t weight_plane_elems(int N, int ldw);
+bool split_weights_f16x3(const float *w, int N, int ldw, unsigned short *out /*3 * weight_plane_elems*/, float *wscale);   // false: not representable
+// canonical f32 features [B][T][F] -> tile-major K-blocked f16 planes (tiles*T*4 rows, Fp columns); *flag (optional) = 1 if a value is non-finite or
+// outside the f16 range
+hipError_t launch_split_features(const float *x, int B, int T, int F, int Fp, int tiles, unsigned short *xh, unsigned short *xl, int *flag,
+                                 hipStream_t s);
 
 // ---- lstm.hip -----------------------------------------------------------------------------
 // One layer, all directions: grid (tiles, dirs).  G holds x_t*W_ih^T + b_ih + b_hh with column
-// dir*4H + u*4 + gate; Y gets h_t at column dir*H + u.  Rows as above.
+// dir*4H + u*4 + gate, tile-blocked (g_index with ldg columns); Y gets h_t at column dir*H + u.  Rows as above.
 struct LstmArgs {
     const float *G; int ldg;
     const float *Whh_packed;     // per dir: register image, see pack_whh()
     const float *Whh_packed16;   // per dir: register image of the 16-sequence kernel (pack_whh16), H = 128 only
-    float *Y; int ldy;
+    float *Y; int ldy;           // f32 output (exact-f32 GEMM mode), or
+    unsigned short *Yh, *Yl;     // the two K-blocked f16 planes (ldy columns) h ~= hi + lo * 2^-11 the f16p GEMM of the next layer reads (Y == nullptr)
     int tiles, T, H, dirs;
     int tile_mode;               // sequences per workgroup: 0 = by batch size, 4, 16 (see launch_lstm)
     // optional carried state (streaming): [dirs][tiles*SEQ_TILE][H], nullptr = zeros / discard
@@ -77,8 +110,8 @@ struct ClsArgs {
     int ld_out;              // row stride of logits / probs (>= T)
 };
 hipError_t launch_classifier(const ClsArgs &a, hipStream_t s);
-// rows (tile-major) -> canonical [B][T][W] copy, for the parity taps
-hipError_t launch_untile(const float *src, int lds_, int W, float *dst, int tiles, int T, int B, hipStream_t s);
+// rows (tile-major) -> canonical [B][T][W] copy, for the parity taps (src_lo != nullptr: src / src_lo are f16 planes)
+hipError_t launch_untile(const void *src, const void *src_lo, int lds_, int W, float *dst, int tiles, int T, int B, hipStream_t s);
 // threshold 0.5 + binary median
 hipError_t launch_median(const float *probs, int B, int T, int kernel, uint8_t *labels, hipStream_t s);
 // 0/1 label rows -> ordered (start frame, first non-speech frame) pairs per row + the number of runs

@@ -257,8 +257,8 @@ class VadRuntime:
             return out[:, :k]
 
     def set_gemm_mode(self, mode: str):
-        """"f32": exact f32 MFMA; "f16x3": 2-way split on the f16 matrix cores (default)."""
-        self._check(self.lib.uvad_set_gemm_mode(self.ctx, {"f32": 0, "f16x3": 1}[mode]))
+        """"f32": exact f32 MFMA; "f16p": 2-way split on the f16 matrix cores (default)."""
+        self._check(self.lib.uvad_set_gemm_mode(self.ctx, {"f32": 0, "f16p": 1}[mode]))
 
     def set_recurrent_tile(self, sequences: int):
         """Sequences per recurrent workgroup: 0 (default) = chosen from the batch size, 4 = latency form, 16 = throughput form."""
