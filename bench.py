@@ -9,7 +9,7 @@ reference) on the named frame shape.
 Workload (config.workload = BASELINE configs[1]): per GPU, B=256 utterances x 10 s of synthetic
 16 kHz audio, 25 ms / 10 ms frames, 64-bin log-mel (Hamming) + PyanNet2 classifier; a "step" is
 one pass of the whole hot path (uvad_forward: PCM resident in HBM -> per-frame logits in HBM) over
-that batch.  The K steps are submitted alternately to two contexts / HIP streams (two steps in flight; every step
+that batch.  The K steps are submitted round-robin to three contexts / HIP streams (three steps in flight; every step
 does all of its work, see main()); --in-flight 1 submits them strictly one after the other (reported as the extra
 object "sequential").  N GPUs = N independent shards of 256 utterances (weak scaling, no data-path
 collective; utterance ids are disjoint across ranks).  value = frames all ranks processed / max
@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU (default = BASELINE cfg 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2, help="steps in flight (1 = strictly sequential submission, 2 = default)")
+    ap.add_argument("--in-flight", type=int, default=3, help="steps in flight (1 = strictly sequential submission, 3 = default)")
     ap.add_argument("--no-sequential", action="store_true", help="skip the extra strictly sequential measurement")
     ap.add_argument("--no-sincnet", action="store_true", help="skip the extra PyanNet (SincNet front end) measurement")
     args = ap.parse_args()
@@ -81,7 +81,7 @@ def main():
     seed_weights(model, 1234, 4.0)
     model.attach_fbank(uvad_amd.FbankConfig(num_filters=N_MELS, window_type="hamming"))
     model = model.to(dev).eval()
-    # Two steps in flight (uvad_amd.ForwardPipeline): the K steps are submitted alternately to two contexts (own weights
+    # Several steps in flight (uvad_amd.ForwardPipeline): the K steps are submitted round-robin to n_fly contexts (own weights
     # copy, workspace and HIP stream each).  Every step is one complete uvad_forward over the batch; only the submission
     # order of INDEPENDENT steps changes: while one step sits in its latency-bound recurrence (128 of the 256 CUs at
     # B=256) the other step's feature kernel and projections run on the idle CUs.  --in-flight 1 = strictly sequential.
@@ -193,8 +193,8 @@ def main():
         "classifier_f32_equivalent_TFLOPs": frames_step * (proj_f + rec_f + head_f) / (elapsed / args.steps) / 1e12,
     }
     out["config"]["steps_in_flight"] = n_fly
-    out["stages_note"] = ("per-stage HIP-event times of one step, measured inside the timed region on that step's own stream; with 2 steps "
-                          "in flight the stages of the two steps overlap, so they do not add up to ms_per_step")
+    out["stages_note"] = ("per-stage HIP-event times of one step, measured inside the timed region on that step's own stream; with several steps "
+                          "in flight the stages of different steps overlap (and slow each other down), so they do not add up to ms_per_step")
 
     if n_fly > 1 and not args.no_sequential:
         out["sequential"] = sequential_latency(rts[0], dev, pcm, min(args.steps, 10), world)

@@ -60,7 +60,8 @@ constexpr int KB_AHI = 0, KB_ALO = BM * 16, KB_W0 = 2 * BM * 16, KB_W1 = KB_W0 +
 template <int NKB, bool OUT_PLANES>   // NKB: 16-deep k-blocks per pipeline stage (1: 14 KiB stages, 2: 28 KiB)
 __global__ __launch_bounds__(256, NKB == 1 ? 4 : 2) void gemm_f16p_kernel(GemmArgs a, int mt, int nt) {
     constexpr int STAGE = NKB * KB_ELEMS;
-    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * STAGE];
+    constexpr int LDS_ELEMS = 2 * STAGE > BM * BN * 2 ? 2 * STAGE : BM * BN * 2;   // the f32 output tile of the blocked epilogue aliases the stages
+    __shared__ __attribute__((aligned(16))) unsigned short lds[LDS_ELEMS];
 
     if (a.gate && (*a.gate != 0) != (a.gate_run_if_set != 0)) return;   // device-side kernel selection (see GemmArgs)
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch, speed only)
@@ -140,10 +141,38 @@ __global__ __launch_bounds__(256, NKB == 1 ? 4 : 2) void gemm_f16p_kernel(GemmAr
         }
     }
 
-    // ---- epilogue: (hi + lo * 2^-11) * 2^-S + bias, activation, straight from the accumulators.  C layout of the 32x32 MFMA:
-    //      register r of lane (fr, fh) = row 8*(r>>2) + 4*fh + (r&3), column fr.
+    // ---- epilogue: (hi + lo * 2^-11) * 2^-S + bias, activation.  C layout of the 32x32 MFMA: register r of lane (fr, fh) =
+    //      row 8*(r>>2) + 4*fh + (r&3), column fr.
     const int col = C0 + wc * 32 + fr;
     const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;
+    if (!OUT_PLANES && a.c_blocked) {
+        // Tile-blocked gate matrix: this workgroup's 128 x 64 tile is ONE contiguous 32 KiB run of G (whole tiles exist for
+        // the padding rows too), so the tile goes through LDS and leaves as unmasked 16-byte stores, 1 KiB per wave-instruction
+        // (dword stores straight from the accumulators measured 2.9 TB/s and did not overlap with the K loops).
+        float *Ct = reinterpret_cast<float *>(lds);
+        __syncthreads();   // every wave is done reading the last stage
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const f32x16 &HI = mi ? hi1 : hi0;
+            const f32x16 &LO = mi ? lo1 : lo0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wr * 64 + mi * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+                Ct[lr * BN + wc * 32 + fr] = __builtin_fmaf(__builtin_fmaf(LO[r], 0.00048828125f, HI[r]), a.wscale, bias);
+            }
+        }
+        __syncthreads();
+        float *dst = a.C + ((size_t)m_tile * (a.N / BN) + n_tile) * (BM * BN);
+#pragma unroll
+        for (int j = 0; j < BM * BN / 4 / 256; ++j) {
+            const int q = tid + 256 * j;
+#ifdef UVAD_F16P_ABL_NOSTORE
+            if (Ct[q * 4] == 12345.678f)
+#endif
+            *reinterpret_cast<float4 *>(dst + (size_t)q * 4) = *reinterpret_cast<const float4 *>(Ct + q * 4);
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const f32x16 &HI = mi ? hi1 : hi0;
@@ -164,12 +193,7 @@ __global__ __launch_bounds__(256, NKB == 1 ? 4 : 2) void gemm_f16p_kernel(GemmAr
                     a.Cl[o] = __builtin_bit_cast(unsigned short, l);
                 }
             } else {
-                const size_t o = a.c_blocked ? g_index(row, col < a.N ? col : 0, a.N) : (size_t)row * a.ldc + col;
-#ifdef UVAD_F16P_ABL_NOSTORE
-                if (row < a.M && col < a.N && v == 12345.678f) a.C[o] = v;
-#else
-                if (row < a.M && col < a.N) a.C[o] = v;
-#endif
+                if (row < a.M && col < a.N) a.C[(size_t)row * a.ldc + col] = v;
             }
         }
     }
@@ -259,6 +283,7 @@ hipError_t launch_gemm_f16p(const GemmArgs &a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     if (!a.Ah || !a.Al || !a.Wsplit16 || a.K <= 0 || (a.K & 31) || a.ldw != a.K) return hipErrorInvalidValue;
     if (a.out_planes ? (!a.Ch || !a.Cl) : !a.C) return hipErrorInvalidValue;
+    if (a.c_blocked && (a.out_planes || a.act != 0 || a.N % BN != 0)) return hipErrorInvalidValue;   // the gate matrix: whole 64-column tiles, no activation
     const int mt = (a.M + BM - 1) / BM, nt = ((a.out_planes ? a.ldc : a.N) + BN - 1) / BN;
     const int grid = ((mt + 7) / 8) * 8 * nt;
     if (a.out_planes)

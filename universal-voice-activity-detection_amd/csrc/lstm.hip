@@ -31,6 +31,11 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #define UVAD_LSTM_PD 4   // gate prefetch depth (steps); 8 fits (252 of 256 registers) and measured the same
 #endif
 
+#ifndef UVAD_LSTM_HR
+#define UVAD_LSTM_HR 8    // h reads kept in flight ahead of the MFMA groups (float4 each).  8: 76 VGPRs + 128 AGPRs = 208 registers per wave, which
+                          // leaves room for one split-f16 GEMM wave (96) beside the two recurrent waves of a SIMD; measured 1 % faster alone than 16
+#endif
+
 constexpr float L2E = 1.4426950408889634f;
 
 // 1 / d for d in [1, 2^127): v_rcp_f32 (1 ulp) + one Newton step -> <= 0.5 ulp + 2^-46
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
         // flight ahead of the MFMA groups (LDS latency under 8 reading waves is several MFMA groups
         // long; a read issued one group ahead stalls the matrix pipe).
         const float *hb = &hbuf[s & 1][jb][0];
-        constexpr int HR = 16;
+        constexpr int HR = UVAD_LSTM_HR;
         float4 hv[HR];
 #ifdef UVAD_ABL_NOLDSREAD   // diagnostic: no h reads at all (results meaningless)
 #pragma unroll
