@@ -120,6 +120,11 @@ int uvad_classify(uvad_ctx *, const float *d_feats, int B, int T, float *d_logit
 int uvad_forward(uvad_ctx *, const float *d_pcm, int B, int64_t S, float *d_logits, float *d_probs,
                  void *d_workspace, size_t ws_bytes, void *stream);
 
+/* The same from 16-bit PCM as read from a wav file (samples scaled by 1/32768): what the reference's predict flow does per batch
+ * (decode audio -> features -> model, src/scripts/predict.py:98 with the offline feature step of ami/utils.py:153-163 folded in). */
+int uvad_forward_i16(uvad_ctx *, const int16_t *d_pcm, int B, int64_t S, float *d_logits, float *d_probs,
+                     void *d_workspace, size_t ws_bytes, void *stream);
+
 /* Debug / parity taps: copy of the last LSTM layer output [B][T][hidden*dirs] and of the last
  * feed-forward activation [B][T][lin_hidden] from the most recent uvad_classify on this
  * workspace (async on stream).  Either pointer may be NULL. */

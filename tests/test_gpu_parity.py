@@ -199,9 +199,33 @@ def test_batch_invariance_full_size_property():
     assert full.std().item() > 0.5
 
 
+def _oracle_windowed(pcm, F, window, sd, scale_cfg, W=80000, keep=48000, frame_shift=0.01):
+    """The reference's cut geometry on the CPU oracle: 5 s windows, tails <= 3 s dropped, features of a kept tail padded with
+    log(1e-10) frames, classifier + 49-tap median per window row, rows laid end to end and cut to ceil(D / shift) + 1."""
+    import math
+    from oracle import c_oracle as co
+    fc = co.default_fbank_cfg(F)
+    win, mel = co.window(window, 400), co.mel_banks(fc)
+    mc = co.ModelCfg(F, 128, 4, 1, 128, 2, 0.01)
+    probs_rows, label_rows = [], []
+    for st in range(0, len(pcm), W):
+        x = pcm[st:st + W]
+        if len(x) <= keep:
+            continue
+        feats = co.fbank(x[None], fc, win, mel)
+        if feats.shape[1] < W // 160:
+            pad = np.full((1, W // 160 - feats.shape[1], F), math.log(1e-10), np.float32)
+            feats = np.concatenate([feats, pad], axis=1)
+        _, p = co.classify(sd, mc, feats)
+        probs_rows.append(p[0])
+        label_rows.append(co.median_filter(p, 49)[0])
+    n = min(int(math.ceil(len(pcm) / 16000 / frame_shift)) + 1, sum(len(r) for r in label_rows))
+    return np.concatenate(probs_rows)[:n], np.concatenate(label_rows)[:n]
+
+
 def test_main_config1_plumbing_30s():
-    """BASELINE cfg 1: one 30 s utterance through main.main(load_config()) -> frame labels + intervals,
-    checked against the oracle run on the same signal."""
+    """BASELINE cfg 1: one 30 s utterance through main.main(load_config()) -> frame labels + intervals, with the reference's
+    cut geometry (six 5 s windows, zero LSTM state in each), checked against the oracle run window by window."""
     import main as entry
     from config.config import load_config
     from uvad_amd.synth import synth_pcm
@@ -213,16 +237,55 @@ def test_main_config1_plumbing_30s():
     res = entry.main(cfg)
     assert len(res) == 1 and res[0]["num_frames"] == 3000
     pcm = synth_pcm(1, 480000, seed=cfg.input.seed)
-    fc = co.default_fbank_cfg(64)
-    feats = co.fbank(pcm, fc, co.window("hamming", 400), co.mel_banks(fc))
     sd = {k: v.numpy() for k, v in tr.seeded_state_dict(64, seed=cfg.weights_seed, scale=cfg.weights_scale).items()}
-    _, probs = co.classify(sd, co.ModelCfg(64, 128, 4, 1, 128, 2, 0.01), feats)
-    assert np.abs(res[0]["probs"] - probs[0]).max() < 2e-3
-    want = co.median_filter(probs, 49)[0]
+    probs, want = _oracle_windowed(pcm[0], 64, "hamming", sd, None)
+    assert np.abs(res[0]["probs"] - probs).max() < 2e-3          # end to end from PCM on the x4 network (fp32 FFT vs f64 DFT features)
     agree = (want == res[0]["labels"]).mean()
     print("label agreement with oracle:", agree, "intervals:", res[0]["intervals"][:3])
     assert agree > 0.995
     assert res[0]["intervals"] == co.intervals(res[0]["labels"], 0.01)
+    # whole-recording mode is a different computation (one BiLSTM pass over 3000 frames): available, not the default
+    cfg.window_seconds = None
+    whole = entry.main(cfg)
+    assert whole[0]["num_frames"] == 3000 and np.abs(whole[0]["probs"] - res[0]["probs"]).max() > 1e-2
+
+
+def test_predict_vad_reference_window_geometry_from_wav(tmp_path):
+    """predict_vad on int16 wav files of awkward lengths (23.7 s: four full windows + a kept 3.7 s tail; 12 s: two windows,
+    the 2 s tail dropped; 4.2 s: one kept tail only; 2 s: nothing) == the oracle run window by window with lhotse's feature
+    padding; several batches in flight (max_duration forces > 1 batch); weights x2 so that the comparison is tight."""
+    import wave
+    from config.config import load_config
+    from src.scripts import predict_vad
+    from uvad_amd.synth import synth_pcm
+    from oracle import torch_ref as tr
+    lens = {"a.wav": int(23.7 * 16000), "b.wav": 12 * 16000, "c.wav": int(4.2 * 16000), "d.wav": 2 * 16000}
+    pcm = {}
+    for k, (name, n) in enumerate(lens.items()):
+        x = synth_pcm(1, n, seed=300 + k)[0]
+        q = np.round(x * 32767.0).astype("<i2")
+        with wave.open(str(tmp_path / name), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(q.tobytes())
+        pcm[name] = q.astype(np.float32) / 32768.0
+    cfg = load_config()
+    cfg.model_dict.encoding_dim = 80                      # the reference's fbank width, povey window
+    cfg.weights_scale = 2.0
+    cfg.max_duration = 12                                  # two 5 s windows per batch -> 3 full-window batches + tails
+    cfg.input.kind = "wav"
+    cfg.input.paths = [str(tmp_path / n) for n in lens]
+    res = {r["recording_id"]: r for r in predict_vad(**cfg)}
+    sd = {k: v.numpy() for k, v in tr.seeded_state_dict(80, seed=cfg.weights_seed, scale=2.0).items()}
+    assert res["d.wav"]["num_frames"] == 0 and res["d.wav"]["intervals"] == []
+    for name, want_frames in (("a.wav", 2371), ("b.wav", 1000), ("c.wav", 421)):
+        probs, labels = _oracle_windowed(pcm[name], 80, "povey", sd, None)
+        r = res[name]
+        assert r["num_frames"] == want_frames == len(labels), (name, r["num_frames"], len(labels))
+        err = np.abs(r["probs"] - probs).max()
+        near = np.abs(probs - 0.5) < 1e-3
+        print(f"{name}: {r['num_frames']} frames, prob err {err:.2e}, {int((r['labels'] != labels).sum())} label differences")
+        assert err < 1e-4
+        if not near.any():
+            assert np.array_equal(r["labels"], labels)
 
 
 def test_library_is_loaded_and_errors_are_loud():

@@ -51,6 +51,8 @@ SIGNATURES = {
                                 C.c_void_p, C.c_size_t, C.c_void_p]),
     "uvad_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_size_t, C.c_void_p]),
+    "uvad_forward_i16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     "uvad_sincnet_configure": (C.c_int, [C.c_void_p, C.POINTER(SincNetCfg)]),
     "uvad_sincnet_num_frames": (C.c_int64, [C.c_void_p, C.c_int64]),
     "uvad_sincnet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int64]),

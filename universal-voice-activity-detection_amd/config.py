@@ -44,6 +44,10 @@ def load_config() -> ConfigDict:
         cfg.model_dict.encoding_dim = 768
 
     cfg.max_duration = 400      # seconds of audio per batch, as the reference's sampler
+    # cut geometry of the reference's recipes (src/datasets/ami/utils.py:107,163): 5 s windows, tails of <= 3 s dropped, features
+    # padded to the window; window_seconds = None runs whole recordings in one pass instead (not what the reference does)
+    cfg.window_seconds = 5.0
+    cfg.min_window_seconds = 3.0
 
     cfg.experiments_dir = os.environ.get("UVAD_EXPERIMENTS_DIR", "experiments")
     cfg.load_checkpoint = False

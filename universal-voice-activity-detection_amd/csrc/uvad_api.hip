@@ -684,8 +684,8 @@ int uvad_classify(uvad_ctx *c, const float *d_feats, int B, int T, float *d_logi
     return classify_impl(c, d_feats, B, T, d_logits, d_probs, ws, ws_bytes, (hipStream_t)stream, true, true);
 }
 
-int uvad_forward(uvad_ctx *c, const float *d_pcm, int B, int64_t S, float *d_logits, float *d_probs,
-                 void *ws, size_t ws_bytes, void *stream) {
+static int forward_impl(uvad_ctx *c, const void *d_pcm, int is_i16, int B, int64_t S, float *d_logits, float *d_probs,
+                        void *ws, size_t ws_bytes, void *stream) {
     if (!c) return UVAD_E_ARG;
     if (!d_pcm || B <= 0 || S <= 0 || !ws) return fail(c, UVAD_E_ARG, "uvad_forward: bad argument");
     if (!c->finalized) return fail(c, UVAD_E_STATE, "uvad_forward: uvad_finalize has not been called");
@@ -699,9 +699,19 @@ int uvad_forward(uvad_ctx *c, const float *d_pcm, int B, int64_t S, float *d_log
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    int r = fbank_impl(c, d_pcm, 0, B, S, feats, stream);
+    int r = fbank_impl(c, d_pcm, is_i16, B, S, feats, stream);
     if (r) return r;
     return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, ws_bytes, s, false, false);   // log-mel values are within +-90
+}
+
+int uvad_forward(uvad_ctx *c, const float *d_pcm, int B, int64_t S, float *d_logits, float *d_probs,
+                 void *ws, size_t ws_bytes, void *stream) {
+    return forward_impl(c, d_pcm, 0, B, S, d_logits, d_probs, ws, ws_bytes, stream);
+}
+
+int uvad_forward_i16(uvad_ctx *c, const int16_t *d_pcm, int B, int64_t S, float *d_logits, float *d_probs,
+                     void *ws, size_t ws_bytes, void *stream) {
+    return forward_impl(c, d_pcm, 1, B, S, d_logits, d_probs, ws, ws_bytes, stream);
 }
 
 int uvad_get_taps(uvad_ctx *c, int B, int T, float *d_lstm_out, float *d_lin_out, const void *ws, void *stream) {

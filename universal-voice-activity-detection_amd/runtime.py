@@ -145,18 +145,25 @@ class VadRuntime:
             return logits, probs
 
     def forward(self, pcm: "torch.Tensor", want_logits=True, want_probs=True):
-        """pcm (B,S) f32 on the GPU -> (logits, probs); features never leave the workspace."""
+        """pcm (B,S) f32 (or int16, as read from a wav file) on the GPU -> (logits, probs); features never leave the workspace."""
         with torch.cuda.device(self.device):
-            pcm = self._dev_f32(pcm, "pcm")
+            if pcm.dtype == torch.int16:
+                if pcm.device != self.device:
+                    raise RuntimeError(f"pcm must be on {self.device}")
+                pcm = pcm.contiguous()
+                fn = self.lib.uvad_forward_i16
+            else:
+                pcm = self._dev_f32(pcm, "pcm")
+                fn = self.lib.uvad_forward
             B, S = pcm.shape
             T = self.num_frames(S)
             ws = self.workspace(B, T)
             logits = torch.empty((B, T), dtype=torch.float32, device=self.device) if want_logits else None
             probs = torch.empty((B, T), dtype=torch.float32, device=self.device) if want_probs else None
-            self._check(self.lib.uvad_forward(self.ctx, pcm.data_ptr(), B, S,
-                                              logits.data_ptr() if want_logits else None,
-                                              probs.data_ptr() if want_probs else None,
-                                              ws.data_ptr(), ws.numel(), self._stream()))
+            self._check(fn(self.ctx, pcm.data_ptr(), B, S,
+                           logits.data_ptr() if want_logits else None,
+                           probs.data_ptr() if want_probs else None,
+                           ws.data_ptr(), ws.numel(), self._stream()))
             self._last_bt = (B, T)
             return logits, probs
 

@@ -1,10 +1,26 @@
 """``predict_vad(**config)``: the reference's predict entry point (src/scripts/predict.py:22-110)
 with its lhotse / Lightning plumbing replaced by a manifest-free source.  Flow kept from the
 reference: seed -> model (checkpoint or seeded weights) -> batches bounded by ``max_duration``
-seconds -> ``VadModel.predict_step`` (probabilities -> 0/1 labels) -> per-recording speech
-intervals (predict.py:472-490).  Feature extraction, which the reference runs offline in
-``task="prepare"`` (ami/utils.py:153-163), is fused in front of the classifier here."""
+seconds -> ``VadModel.predict_step`` semantics (probabilities -> threshold 0.5 -> median filter ->
+0/1 labels) -> per-recording speech intervals (predict.py:472-490).
+
+Cut geometry (``window_seconds``, default = the reference's 5.0):
+  the reference never shows the model a whole recording.  Every recording is cut into 5 s windows,
+  a tail of <= 3 s is dropped (``cut_into_windows(duration=5).filter(lambda cut: cut.duration > 3)``,
+  src/datasets/ami/utils.py:107), features are computed per window and padded to 5 s
+  (``.pad(duration=5.0)``, ami/utils.py:163: lhotse pads log-mel features with log(1e-10)), the BiLSTM
+  starts from zero state in every window, the median filter runs per window row
+  (vad_engine.py:204-211) and the rows are laid end to end and cut to ceil(duration / frame_shift) + 1
+  frames per recording (predict.py:451-458).  ``window_seconds=5.0`` reproduces exactly that, so
+  a trained checkpoint gives the reference's labels; ``window_seconds=None`` runs the model over whole
+  recordings instead (one BiLSTM pass per recording: different numbers for anything longer than a
+  window -- an explicit option, not the default).
+
+Every batch goes through the fused hot path: PCM (int16 straight from the wav file, or f32) ->
+``uvad_forward[_i16]`` (features stay in the workspace) -> ``uvad_median_filter`` -> ``uvad_label_runs``;
+several batches are kept in flight with ``ForwardPipeline`` when there is more than one."""
 import json
+import math
 import os
 import wave
 from typing import List
@@ -13,9 +29,12 @@ import numpy as np
 import torch
 
 from .engine import VadModel
-from .features import Fbank, FbankConfig
+from .features import FbankConfig
+from .pipeline import ForwardPipeline
 from .postprocess import labels_to_intervals_batch, median_filter
 from .synth import seed_weights, synth_pcm
+
+LOG_EPS_PAD = math.log(1e-10)   # lhotse's padding value for log-mel features (LOG_EPSILON)
 
 
 def read_wav_int16(path: str, sample_rate: int = 16000) -> np.ndarray:
@@ -37,6 +56,17 @@ def _resolve_device(name: str) -> torch.device:
                        "the CPU restatement lives in oracle/ and is test infrastructure")
 
 
+def cut_into_windows(num_samples: int, window: int, min_keep: int):
+    """[(start, length)] of the reference's cuts of one recording: consecutive `window`-sample pieces, the last one
+    shorter; pieces of <= min_keep samples are dropped (ami/utils.py:107)."""
+    out = []
+    for start in range(0, num_samples, window):
+        n = min(window, num_samples - start)
+        if n > min_keep:
+            out.append((start, n))
+    return out
+
+
 def predict_vad(**kwargs):
     assert kwargs["model_name"] in kwargs["supported_models"], \
         f"Invalid model {kwargs['model_name']}. Model should be one of {kwargs['supported_models']}"
@@ -49,6 +79,7 @@ def predict_vad(**kwargs):
     device = _resolve_device(kwargs["device"])
     frame_shift = kwargs["frame_shift"]
     model_dict = dict(kwargs["model_dict"])
+    sr = 16000
 
     if kwargs["load_checkpoint"]:
         model = VadModel.load_from_checkpoint(checkpoint_path=kwargs["checkpoint_path"],
@@ -57,51 +88,118 @@ def predict_vad(**kwargs):
         model = VadModel(model_name=kwargs["model_name"], model_dict=model_dict)
         seed_weights(model.model, kwargs.get("weights_seed", 1234), kwargs.get("weights_scale", 4.0))
     model = model.to(device).eval()
-
-    extractor = None
+    net = model.model
     if not sincnet:
-        fb_cfg = FbankConfig(sampling_rate=16000, num_filters=model.model.encoding_dim,
-                             window_type=kwargs.get("window_type", "povey"), frame_shift=frame_shift, device="cuda")
-        extractor = Fbank(fb_cfg)
+        net.attach_fbank(FbankConfig(sampling_rate=sr, num_filters=net.encoding_dim, window_type=kwargs.get("window_type", "povey"),
+                                     frame_shift=frame_shift, device="cuda"))
 
     src = kwargs["input"]
     recs: List[dict] = []
     if src["kind"] == "wav":
         for p in src["paths"]:
-            recs.append({"id": os.path.basename(p), "pcm": read_wav_int16(p).astype(np.float32) / 32768.0})
+            recs.append({"id": os.path.basename(p), "pcm": read_wav_int16(p)})             # int16: converted on the GPU
     elif src["kind"] == "synthetic":
-        S = int(round(src["seconds"] * 16000))
+        S = int(round(src["seconds"] * sr))
         pcm = synth_pcm(src["num_utterances"], S, seed=src["seed"])
         recs = [{"id": f"synthetic-{src['seed'] + i}", "pcm": pcm[i]} for i in range(pcm.shape[0])]
     else:
         raise ValueError(f"unknown input kind {src['kind']!r}")
 
-    # batches: equal-length recordings together, at most max_duration seconds per batch
-    results = []
-    order = sorted(range(len(recs)), key=lambda i: len(recs[i]["pcm"]))
-    i = 0
+    window_s = kwargs.get("window_seconds", 5.0)
+    if sincnet and window_s is not None and abs(window_s - 5.0) > 1e-9:
+        raise NotImplementedError("the SincNet path keeps the reference's fixed 5 s cuts")
+    # ---- pieces the model sees: (recording index, start sample, length)
+    pieces = []
+    for ri, r in enumerate(recs):
+        n = len(r["pcm"])
+        if window_s is None:
+            pieces.append((ri, 0, n))
+        else:
+            for st, ln in cut_into_windows(n, int(round(window_s * sr)), int(round(kwargs.get("min_window_seconds", 3.0) * sr))):
+                pieces.append((ri, st, ln))
+    W = None if window_s is None else int(round(window_s * sr))
+    med_window = 0.02 if net.encoding_dim == 768 else 0.01   # vad_engine.py:207-208
+
+    # ---- batches: pieces of equal length together, at most max_duration seconds of audio per batch
+    order = sorted(range(len(pieces)), key=lambda i: (-pieces[i][2], i))
+    batches, i = [], 0
     while i < len(order):
-        n = len(recs[order[i]]["pcm"])
+        n = pieces[order[i]][2]
         group = [order[i]]
-        while (i + len(group) < len(order) and len(recs[order[i + len(group)]]["pcm"]) == n
-               and (len(group) + 1) * n / 16000.0 <= kwargs["max_duration"]):
+        while (i + len(group) < len(order) and pieces[order[i + len(group)]][2] == n
+               and (len(group) + 1) * n / float(sr) <= kwargs["max_duration"]):
             group.append(order[i + len(group)])
         i += len(group)
-        batch_pcm = torch.from_numpy(np.stack([recs[j]["pcm"] for j in group])).to(device)
-        # one forward pass per batch; labels exactly as VadModel.predict_step derives them from the probabilities
-        # (vad_engine.py:204-211: threshold 0.5 + median filter, 49 taps unless encoding_dim == 768)
+        batches.append(group)
+
+    rt = net.runtime(device)
+    pipe = None
+    if not sincnet and len(batches) > 1:
+        pipe = ForwardPipeline(net, device, depth=min(3, len(batches)))   # kept tails (n < W) take the unfused branch below
+
+    def stack(group):
+        rows = [recs[pieces[j][0]]["pcm"][pieces[j][1]:pieces[j][1] + pieces[j][2]] for j in group]
+        return torch.from_numpy(np.stack(rows)).to(device)
+
+    piece_probs = [None] * len(pieces)
+    pending = []
+    for group in batches:
+        n = pieces[group[0]][2]
+        x = stack(group)
         if sincnet:   # (batch, samples); the model consumes raw audio, channel axis added as in vad_engine.py:252-255
-            probs = model(batch_pcm.unsqueeze(1)).squeeze(-1)
+            xf = x.float() / 32768.0 if x.dtype == torch.int16 else x
+            probs = model(xf.unsqueeze(1)).squeeze(-1)
+        elif W is not None and n < W:
+            # a kept tail (3 s < length < 5 s): features of the samples that exist, then lhotse's padding frames up to the
+            # window's frame count, then the classifier (the reference pads FEATURES, not audio)
+            feats = rt.fbank(x)
+            T_full = rt.num_frames(W)
+            padded = torch.full((feats.shape[0], T_full, feats.shape[2]), LOG_EPS_PAD, dtype=torch.float32, device=device)
+            padded[:, :feats.shape[1]] = feats
+            _, probs = rt.classify(padded, want_logits=False)
+        elif pipe is not None:
+            pending.append((group, pipe.submit(x, want_logits=False, want_probs=True)))
+            continue
         else:
-            feats = torch.stack(extractor.extract_batch(list(batch_pcm), sampling_rate=16000))
-            probs = model(feats).squeeze(-1)
-        labels = median_filter(probs, window=0.02 if model.model.encoding_dim == 768 else 0.01)   # (B, T) 0/1
-        intervals = labels_to_intervals_batch(labels, frame_shift)   # run-length walk on the GPU (uvad_label_runs)
-        labels_h, probs_h = labels.cpu().numpy(), probs.cpu().numpy()
+            _, probs = rt.forward(x, want_logits=False)          # fused PCM -> probabilities (uvad_forward / uvad_forward_i16)
         for r, j in enumerate(group):
-            results.append({"recording_id": recs[j]["id"], "num_frames": int(labels_h.shape[1]),
-                            "labels": labels_h[r].astype(np.uint8), "probs": probs_h[r],
-                            "intervals": intervals[r]})
+            piece_probs[j] = probs[r]
+    for group, p in pending:
+        _, probs = p.result()
+        for r, j in enumerate(group):
+            piece_probs[j] = probs[r]
+    if pipe is not None:
+        pipe.close()
+
+    # ---- labels per piece exactly as VadModel.predict_step derives them (vad_engine.py:204-211: threshold 0.5 + median
+    #      filter per row), then the rows of a recording laid end to end (predict.py:451-458)
+    results = []
+    for ri, r in enumerate(recs):
+        mine = [j for j in range(len(pieces)) if pieces[j][0] == ri]
+        if not mine:
+            results.append({"recording_id": r["id"], "num_frames": 0, "labels": np.zeros(0, np.uint8), "probs": np.zeros(0, np.float32),
+                            "intervals": []})
+            continue
+        rows_l, rows_p = [], []
+        by_len = {}
+        for j in mine:
+            by_len.setdefault(piece_probs[j].shape[0], []).append(j)
+        lab_of = {}
+        for T, js in by_len.items():
+            lab = median_filter(torch.stack([piece_probs[j] for j in js]), window=med_window)   # (n, T) 0/1 on the GPU
+            for k, j in enumerate(js):
+                lab_of[j] = lab[k]
+        for j in mine:
+            rows_l.append(lab_of[j])
+            rows_p.append(piece_probs[j])
+        labels = torch.cat(rows_l)
+        probs = torch.cat(rows_p)
+        if window_s is not None and not sincnet:   # (the SincNet script of the reference, predict_sincnet.py, maps frames by receptive field)
+            keep = min(int(math.ceil(len(r["pcm"]) / sr / frame_shift)) + 1, labels.shape[0])
+            labels, probs = labels[:keep], probs[:keep]
+        intervals = labels_to_intervals_batch(labels.unsqueeze(0), frame_shift)[0]   # run-length walk on the GPU (uvad_label_runs)
+        results.append({"recording_id": r["id"], "num_frames": int(labels.shape[0]), "labels": labels.cpu().numpy().astype(np.uint8),
+                        "probs": probs.cpu().numpy(), "intervals": intervals})
     results.sort(key=lambda r: r["recording_id"])
 
     out_dir = kwargs.get("predict_output_dir") or ""
