@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=3, help="steps in flight (1 = strictly sequential submission, 3 = default)")
     ap.add_argument("--no-sequential", action="store_true", help="skip the extra strictly sequential measurement")
     ap.add_argument("--no-sincnet", action="store_true", help="skip the extra PyanNet (SincNet front end) measurement")
+    ap.add_argument("--scatter", action="store_true",
+                    help="extra measurement (N > 1): root-resident PCM scattered to the ranks (RCCL over xGMI) on a side stream, "
+                         "double-buffered against the compute; reported as the extra object 'scatter', never in 'value'")
     args = ap.parse_args()
 
     import uvad_amd
@@ -198,6 +201,8 @@ def main():
 
     if n_fly > 1 and not args.no_sequential:
         out["sequential"] = sequential_latency(rts[0], dev, pcm, min(args.steps, 10), world)
+    if args.scatter:
+        out["scatter"] = scatter_leg(rt, dev, B, S, rank, world, min(args.steps, 10))
     if rank == 0 and world == 1 and not args.no_sincnet:
         out["pyannet_sincnet"] = sincnet_throughput(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -235,6 +240,51 @@ def sequential_latency(rt, dev, pcm, steps, world):
             "roofline": {"kernel": "lstm_rec_kernel<128, 8>", "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": launch_ms},
             "note": "same step, one at a time on one stream; not the headline value"}
+
+
+def scatter_leg(rt, dev, B, S, rank, world, steps):
+    """Extra, NOT the headline value (root-resident corpus mode): rank 0 holds the PCM of the global batch
+    (world x B utterances), every step it is scattered by utterance id (i mod world) with ONE collective -- RCCL scatter, root
+    egress over all xGMI links at once -- on a side stream into the second of two buffers while the ranks run the hot path on the
+    first.  Reports the scatter alone (ms, root egress GB/s) and the step time with the scatter overlapped."""
+    import torch.distributed as tdist
+    from uvad_amd import dist as udist
+    from uvad_amd.synth import synth_pcm_device
+    n_total = world * B
+    backend = tdist.get_backend() if world > 1 else "none"
+    host_staged = backend == "gloo"     # rehearsal on one GPU: gloo moves host tensors
+    full = synth_pcm_device(n_total, S, seed=43, device=dev) if rank == 0 else None
+    like = torch.empty((1, S), dtype=torch.float32, device="cpu" if host_staged else dev)
+
+    def scatter():
+        src = (full.cpu() if host_staged else full) if rank == 0 else None
+        part = udist.scatter_rows(src, n_total, rank, world, like=like)
+        return part.to(dev, non_blocking=True) if host_staged else part
+
+    bufs = [scatter(), None]
+    torch.cuda.synchronize(dev); udist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bufs[1] = scatter()
+    torch.cuda.synchronize(dev); udist.barrier()
+    t_sc = udist.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 and not host_staged else None) / steps
+    side = torch.cuda.Stream(device=dev)
+    rt.forward(bufs[0], want_probs=False)
+    torch.cuda.synchronize(dev); udist.barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        with torch.cuda.stream(side):
+            bufs[(k + 1) & 1] = scatter()                       # next batch's shard arrives while this one is processed
+        rt.forward(bufs[k & 1], want_probs=False)
+        torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev); udist.barrier()
+    t_ov = udist.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 and not host_staged else None) / steps
+    egress = (n_total - udist.shard_count(n_total, 0, world)) * S * 4
+    return {"backend": backend + (" (host-staged rehearsal, not xGMI)" if host_staged else ""), "global_batch": n_total,
+            "scatter_ms": t_sc * 1e3, "root_egress_GBs": egress / t_sc / 1e9 if world > 1 else None,
+            "step_ms_with_scatter_overlapped": t_ov * 1e3,
+            "frames_per_s_with_scatter": n_total * rt.num_frames(S) / t_ov,
+            "note": "root-resident PCM mode; the headline 'value' uses rank-local synthetic shards (no data-path collective)"}
 
 
 def sincnet_throughput(dev, B=256, S=80000, reps=5):

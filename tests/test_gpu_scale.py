@@ -165,3 +165,30 @@ def test_cfg4_large_batch_throughput_recurrence_and_shard_invariance():
             auto, _ = rt.forward(pcm[idx].contiguous(), want_probs=False)
             assert rt.recurrent_tile() == (16 if len(idx) >= 1024 else 4)
             assert torch.equal(auto, part) if rt.recurrent_tile() == 16 else (auto - part).abs().max() < LOGIT_TOL
+
+
+def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
+    """The N > 1 leg of bench.py rehearsed with two ranks on this one GPU (gloo instead of RCCL, one process per rank as the driver
+    launches it): rendezvous on 127.0.0.1, disjoint utterance shards, barrier + max-over-ranks timing, one JSON line from rank 0
+    with the whole-job value, and the root-resident scatter mode (--scatter).  RCCL itself with N > 1 ranks needs a multi-GPU node."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, UVAD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "32",
+           "--no-cpu-baseline", "--no-sincnet", "--no-sequential", "--in-flight", "1", "--scatter"]
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout                          # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4 and d["value"] > 0
+    assert d["config"]["utterances_per_gpu"] == 32 and d["config"]["sharding"] == "utterance-shard x2"
+    assert abs(d["value"] - 2 * 32 * 1000 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6     # whole-job frames over the max-over-ranks time
+    assert "rank 0/2" in p.stderr and "rank 1/2" in p.stderr
+    sc = d["scatter"]
+    assert sc["global_batch"] == 64 and sc["scatter_ms"] > 0 and sc["frames_per_s_with_scatter"] > 0 and "gloo" in sc["backend"]
+    print("2-rank rehearsal:", {k: d[k] for k in ("value", "ms_per_step")}, sc)

@@ -13,7 +13,11 @@ ap.add_argument("--streams", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--int16", action="store_true")
+ap.add_argument("--lib", default=None, help="another build of libuvad.so (A/B on one box)")
 args = ap.parse_args()
+if args.lib:
+    from uvad_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(args.lib)
 dev = torch.device("cuda:0")
 B, C, F = args.streams, 16000, 64
 rt = uvad_amd.Fbank(uvad_amd.FbankConfig(num_filters=F, window_type="hamming"))._runtime(dev)

@@ -6,17 +6,20 @@
 // (B,T,512) frame tensor and the complex spectrum in HBM: >5x the algorithmic traffic.)
 //
 // gfx950 design
-//   * a workgroup (4 waves) owns FR_WG = 40 consecutive frames of one utterance: the
-//     39*160+400 PCM samples they cover are loaded ONCE (16-byte coalesced loads, reflection
+//   * a workgroup (4 waves) owns FR_WG = 24 consecutive frames of one utterance: the
+//     23*160+400 PCM samples they cover are loaded ONCE (16-byte coalesced loads, reflection
 //     handled at the utterance edges) into an LDS tile; neighbouring workgroups re-read only the
-//     240-sample overlap (4 %).
+//     240-sample overlap (6 %, absorbed by L2).
 //   * a wave transforms TWO frames at a time as the real and imaginary part of one 512-point
 //     complex FFT, 8 points per lane, as three radix-8 passes (512 = 8*8*8) held in registers;
 //     the two re-distributions between passes go through a padded per-wave LDS scratch with
 //     wave-local ordering only (no workgroup barrier in the loop).
 //   * the two spectra are separated with the conjugate-symmetry identity, |.|^2 goes to LDS as
-//     (frameA, frameB) pairs, and lane m accumulates mel filter m over its (start,len) band with
-//     one ds_read_b64 per bin serving both frames; 64 lanes write 256 contiguous bytes per frame.
+//     (frameA, frameB) pairs (over the transpose scratch), and lane m accumulates mel filter m over its
+//     (start,len) band, two bins per LDS instruction; 64 lanes write 256 contiguous bytes per frame.
+//   The kernel is bound by vector-instruction issue, not by HBM: ~650 instructions per lane and frame pair
+//   (three radix-8 passes, two transposes, framing, mel) put the ceiling near 1.5 G frames/s = 17 % of the
+//   8.9 G frames/s the HBM roofline would allow.
 //   Algorithmic HBM bytes per frame: 640 read (320 for int16 PCM) + 4*n_mels written.
 #include "uvad_internal.h"
 
@@ -25,11 +28,17 @@ namespace uvad {
 namespace {
 
 constexpr int NFFT = 512;
-constexpr int PAIRS_PER_WAVE = 5;
+#ifndef UVAD_FB_PAIRS
+#define UVAD_FB_PAIRS 3    // frame pairs per wave: 24 frames per workgroup (16 KiB PCM tile; with the scratch ~43 KiB of LDS -> 3 workgroups per CU)
+#endif
+#ifndef UVAD_FB_MINWAVES
+#define UVAD_FB_MINWAVES 4   // <= 128 VGPRs (no spills): register occupancy never the limiter
+#endif
+constexpr int PAIRS_PER_WAVE = UVAD_FB_PAIRS;
 constexpr int FR_WG = 4 * 2 * PAIRS_PER_WAVE;  // frames per workgroup
 constexpr int ZB_LD = 9;                       // padded row (8 complex + 1) of the transpose scratch
 constexpr int ZB_ELEMS = 64 * ZB_LD;           // 576 complex >= 512
-constexpr int PB_ELEMS = 264;                  // 257 (powerA, powerB) pairs, padded
+constexpr int PB_ELEMS = 0;                    // the 257 (powerA, powerB) pairs reuse the first 264 slots of the transpose scratch
 
 __device__ __forceinline__ void wave_lds_fence() {
     // Hand-off through the wave's own LDS scratch.  The hardware executes one wave's DS operations in
@@ -121,7 +130,7 @@ __device__ __forceinline__ float pcm_at(const void *row, int64_t i) {
 #endif
 
 template <bool I16>
-__global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *__restrict__ tw512) {
+__global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs a, const float2 *__restrict__ tw512) {
 #ifdef UVAD_FB_STAMP
     unsigned long long fb_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fb_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(fb_prev)::"memory");
@@ -129,7 +138,8 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = a.frame_len, sh = a.frame_shift, F = a.n_mels;
     const int raw_pad = (((FR_WG - 1) * sh + L) + 3) & ~3;
-    const int melw_pad = (a.tab.mel_stride * F + 3) & ~3;
+    const int mel_pairs = (a.tab.mel_stride + 1) / 2;          // bins per filter rounded up to pairs (zero weights in the padding)
+    const int melw_pad = (2 * mel_pairs * F + 3) & ~3;
     float *raw = smem;
     float *melw = raw + raw_pad;
     float2 *wscr = reinterpret_cast<float2 *>(melw + melw_pad);
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
     // ---- stage the PCM tile (reflect at the utterance edges) --------------------------------
     // All loads of the tile are issued before the first LDS write (ST_IT chunks of 4 samples per
     // thread in flight): a load -> wait -> store loop would pay the HBM latency once per chunk.
-    constexpr int ST_IT = 8;   // 8 * 1024 samples >= (FR_WG - 1) * 160 + 400 for the reference geometry
+    constexpr int ST_IT = ((FR_WG - 1) * 160 + 400 + 1023) / 1024;   // one round covers the tile at the reference geometry (25 ms / 10 ms)
     for (int base = 0; base < need; base += ST_IT * 1024) {
         float4 v[ST_IT];
 #pragma unroll
@@ -193,9 +203,9 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
         }
     }
     // mel weights transposed to [bin-in-band][filter] so lane m reads conflict-free
-    for (int i = tid; i < a.tab.mel_stride * F; i += 256) {
+    for (int i = tid; i < 2 * mel_pairs * F; i += 256) {
         const int m = i % F, r = i / F;
-        melw[i] = a.tab.mel_w[(size_t)m * a.tab.mel_stride + r];
+        melw[i] = r < a.tab.mel_stride ? a.tab.mel_w[(size_t)m * a.tab.mel_stride + r] : 0.0f;
     }
 
     // ---- per-lane constants -------------------------------------------------------------------
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
 
     FB_STAMP(0)   // [0] tile staging + per-lane constants
     float2 *zb = wscr + (size_t)wave * (ZB_ELEMS + PB_ELEMS);
-    float2 *pb = zb + ZB_ELEMS;
+    float2 *pb = zb;   // written only after every spectrum value of the pair has been read into registers
     const float inv_len = 1.0f / (float)L;
 
     for (int q = 0; q < PAIRS_PER_WAVE; ++q) {
@@ -320,38 +330,48 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a, const float2 *_
         wave_lds_fence();
         FB_STAMP(4)   // [4] pass 3 + spectrum to LDS
         // ---- split the two real spectra, power: A = (Z[k] + conj Z[N-k])/2, B = (Z[k] - conj Z[N-k])/(2i)
+        // (all reads first, then the power pairs overwrite the scratch)
+        {
+            float2 pw[5];
 #pragma unroll
-        for (int d = 0; d < 5; ++d) {
-            const int k = lane + 64 * d;
-            if (d < 4 || lane == 0) {
-                const float2 z = zb[k];
-                const float2 w = zb[(NFFT - k) & (NFFT - 1)];
+            for (int d = 0; d < 5; ++d) {
+                const int k = lane + 64 * d;
+                const int kc = d < 4 ? k : (lane == 0 ? 256 : 0);
+                const float2 z = zb[kc];
+                const float2 w = zb[(NFFT - kc) & (NFFT - 1)];
                 const float ar = z.x + w.x, ai = z.y - w.y;
                 const float br = z.y + w.y, bi = z.x - w.x;
-                pb[k] = make_float2(0.25f * (ar * ar + ai * ai), 0.25f * (br * br + bi * bi));
+                pw[d] = make_float2(0.25f * (ar * ar + ai * ai), 0.25f * (br * br + bi * bi));
             }
+            wave_lds_fence();
+#pragma unroll
+            for (int d = 0; d < 5; ++d)
+                if (d < 4 || lane == 0) pb[lane + 64 * d] = pw[d];
         }
         wave_lds_fence();
         FB_STAMP(5)   // [5] split + power
         // ---- mel band sums + log; lane = filter ----------------------------------------------------
-        // Uniform trip count (the longest band, zero-padded weights) and 4 bins per iteration keep 8 LDS
-        // reads in flight instead of one dependent read per bin; bins past a filter's band meet zero weights.
+        // Uniform trip count (the longest band, zero-padded weights), two bins per LDS instruction: the weights of bins i, i+1
+        // are F floats apart (ds_read2_b32), their power pairs adjacent (ds_read2_b64, no alignment requirement).  No clamp of
+        // the bin index: a band that runs past bin 256 reads this pair's own spectrum values from the scratch (finite) against
+        // zero weights.
         for (int ps = 0; ps < nfilt_pass; ++ps) {
             const int m = lane + 64 * ps;
             const int mm = m < F ? m : F - 1;
             const int st = ps == 0 ? mst0v : mst1;   // n_mels <= 128 (checked by uvad_create): no global load in this loop
-            float ea = 0.f, eb = 0.f;
-            for (int i0 = 0; i0 < a.tab.mel_stride; i0 += 4) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = i0 + e;
-                    const float wv = i < a.tab.mel_stride ? melw[i * F + mm] : 0.f;
-                    const int k = st + i < NFFT / 2 ? st + i : NFFT / 2;
-                    const float2 pv = pb[k];
-                    ea = __builtin_fmaf(wv, pv.x, ea);
-                    eb = __builtin_fmaf(wv, pv.y, eb);
-                }
+            float ea = 0.f, eb = 0.f, ea2 = 0.f, eb2 = 0.f;
+            const float *wp = melw + mm;
+            const float2 *pp = pb + st;
+            for (int i = 0; i < mel_pairs; ++i) {
+                const float w0 = wp[(2 * i) * F], w1 = wp[(2 * i + 1) * F];
+                const float2 p0 = pp[2 * i], p1 = pp[2 * i + 1];
+                ea = __builtin_fmaf(w0, p0.x, ea);
+                eb = __builtin_fmaf(w0, p0.y, eb);
+                ea2 = __builtin_fmaf(w1, p1.x, ea2);
+                eb2 = __builtin_fmaf(w1, p1.y, eb2);
             }
+            ea += ea2;
+            eb += eb2;
             if (m < F) {
                 float *o = a.feats + ((size_t)b * a.T + t0 + fa) * F + m;
                 o[0] = logf(fmaxf(ea, a.log_floor));   // ocml logf (<= 1 ulp), not the 2-ulp-of-log2 __logf: two per lane and frame pair, nothing next to the FFT
@@ -393,7 +413,7 @@ __global__ __launch_bounds__(256) void stream_stage_kernel(const float *chunk_pc
 
 size_t fbank_lds_bytes(const FbankArgs &a) {
     const size_t raw_pad = (size_t)((((FR_WG - 1) * a.frame_shift + a.frame_len) + 3) & ~3);
-    const size_t melw_pad = (size_t)((a.tab.mel_stride * a.n_mels + 3) & ~3);
+    const size_t melw_pad = (size_t)((2 * ((a.tab.mel_stride + 1) / 2) * a.n_mels + 3) & ~3);
     return (raw_pad + melw_pad) * sizeof(float) + 4 * (size_t)(ZB_ELEMS + PB_ELEMS) * sizeof(float2);
 }
 
