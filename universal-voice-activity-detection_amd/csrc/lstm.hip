@@ -360,6 +360,9 @@ __global__ __launch_bounds__(512) void lstm_rec16_kernel(LstmArgs a) {
 #pragma unroll
         for (int i = 0; i < KS / 4; ++i) hv[i] = *reinterpret_cast<const float4 *>(hb + 4 * i);
 
+        // k-major over four independent accumulators (row blocks).  A variant with the row blocks one after the other and the
+        // cell update of block rb staged between the MFMA groups of block rb + 1 measured the same 5.7 us per step at
+        // B = 4096 (the kernel is bound by the f32 matrix pipe, 76 % busy), so the simple form stays.
         f32x4 acc[RB];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc[rb] = gq[u2][rb];
@@ -382,17 +385,19 @@ __global__ __launch_bounds__(512) void lstm_rec16_kernel(LstmArgs a) {
             for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[rb * KS + 4 * i + 3], hv[i].w, acc[rb], 0, 0, 0);
         }
         const size_t yrow = row0 + (size_t)t * SEQ_TILE;
+        float hnew[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) hnew[rb] = lstm_cell(acc[rb], c[rb]);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            const float h = lstm_cell(acc[rb], c[rb]);
             const int u = ubase + 4 * rb;
-            hbuf[(s + 1) & 1][u >> 5][j][u & 31] = h;
+            hbuf[(s + 1) & 1][u >> 5][j][u & 31] = hnew[rb];
             if (live) {
                 if constexpr (PLANES) {
                     const size_t yo = plane_index(yrow, (int)ycol + 4 * rb, a.ldy);
-                    store_planes(a.Yh + yo, a.Yl + yo, h);
+                    store_planes(a.Yh + yo, a.Yl + yo, hnew[rb]);
                 } else {
-                    a.Y[yrow * a.ldy + ycol + 4 * rb] = h;
+                    a.Y[yrow * a.ldy + ycol + 4 * rb] = hnew[rb];
                 }
             }
         }
@@ -402,6 +407,8 @@ __global__ __launch_bounds__(512) void lstm_rec16_kernel(LstmArgs a) {
 }
 
 }  // namespace
+
+constexpr double REC16_ROUND_COST = 3.0;   // time of one round of the 16-sequence form / one round of the 4-sequence form
 
 size_t whh_packed_elems(int H) { return (size_t)4 * H * H; }
 
@@ -434,8 +441,9 @@ void pack_whh16(const float *w_hh, int H, float *out) {
                 }
 }
 
-// tile_mode 0: 16 sequences per workgroup when that still gives every CU a workgroup twice over (tiles*dirs >= 512,
-// i.e. B >= 1024 bidirectional), else 4; 4 / 16 force either.  *tile_used (optional) reports the choice.
+// tile_mode 0: the form with the smaller estimated time.  One workgroup per CU at a time for both forms (registers), so a
+// launch takes ceil(workgroups / CUs) rounds; a round of the 16-sequence form costs REC16_ROUND_COST rounds of the
+// 4-sequence form (measured at B = 1024 ... 4096, profiles/README.md).  4 / 16 force either.  *tile_used reports the choice.
 hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
     if (tile_used) *tile_used = 0;
     if (a.tiles <= 0 || a.T <= 0) return hipSuccess;
@@ -443,7 +451,10 @@ hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
     if (a.tile_mode == 16 && !can16) return hipErrorInvalidValue;
     const bool planes = a.Y == nullptr;
     if (planes && (!a.Yh || !a.Yl)) return hipErrorInvalidValue;
-    if (can16 && (a.tile_mode == 16 || (a.tile_mode == 0 && a.tiles * a.dirs >= 512))) {
+    const int ncu = a.n_cu > 0 ? a.n_cu : 256;
+    const long rounds4 = ((long)a.tiles * a.dirs + ncu - 1) / ncu, rounds16 = ((long)((a.tiles + 3) / 4) * a.dirs + ncu - 1) / ncu;
+    const bool pick16 = (double)rounds16 * REC16_ROUND_COST < (double)rounds4;
+    if (can16 && (a.tile_mode == 16 || (a.tile_mode == 0 && pick16))) {
         if (tile_used) *tile_used = 16;
         const dim3 grid16((a.tiles + 3) / 4, a.dirs);
         if (planes) hipLaunchKernelGGL((lstm_rec16_kernel<128, true>), grid16, dim3(512), 0, s, a);

@@ -634,7 +634,7 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.Whh_packed16 = L.w_hh16; r.ldy = w.Wd;
         if (y_planes(k)) { r.Yh = hi_of(w.off_Y[k & 1]); r.Yl = lo_of(w.off_Y[k & 1], w.Wd); }
         else r.Y = Yf(k & 1);
-        r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D; r.tile_mode = ss ? 4 : c->rec_tile_mode;
+        r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D; r.tile_mode = ss ? 4 : c->rec_tile_mode; r.n_cu = c->n_cu;
         if (ss) {   // carried (h, c) of this layer, updated in place
             r.h0 = r.hN = ss->h + (size_t)k * ss->layer_stride;
             r.c0 = r.cN = ss->c + (size_t)k * ss->layer_stride;

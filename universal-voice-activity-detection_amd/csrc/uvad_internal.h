@@ -88,7 +88,8 @@ struct LstmArgs {
     float *Y; int ldy;           // f32 output (exact-f32 GEMM mode), or
     unsigned short *Yh, *Yl;     // the two K-blocked f16 planes (ldy columns) h ~= hi + lo * 2^-11 the f16p GEMM of the next layer reads (Y == nullptr)
     int tiles, T, H, dirs;
-    int tile_mode;               // sequences per workgroup: 0 = by batch size, 4, 16 (see launch_lstm)
+    int tile_mode;               // sequences per workgroup: 0 = by estimated time, 4, 16 (see launch_lstm)
+    int n_cu;                    // compute units of the device (0 = 256)
     // optional carried state (streaming): [dirs][tiles*SEQ_TILE][H], nullptr = zeros / discard
     const float *h0, *c0; float *hN, *cN;
 };
