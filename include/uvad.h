@@ -224,11 +224,15 @@ int uvad_set_gemm_mode(uvad_ctx *, int mode);
 /* How many sequences one recurrent workgroup owns (the time loop of nn.LSTM, PyanNet2.py:169-172):
  *   4   latency form (v_mfma_f32_4x4x1): B/4 x directions workgroups, the right one up to a few hundred sequences;
  *   16  throughput form (v_mfma_f32_16x16x4, hidden_size 128 only): fewer, heavier workgroups for B >= 1024;
- *   0   (default) chosen per call from the batch size (16 when B/4 x directions >= 512).
+ *   0   (default) chosen per call: the form with fewer estimated rounds of workgroups over the CUs (uvad_recurrent_tile_for).
  * uvad_get_recurrent_tile returns what the most recent uvad_classify / uvad_forward* call launched (4 or 16; 0 before
  * the first call).  Results agree to rounding between the two (tests/test_gpu_parity.py). */
 int uvad_set_recurrent_tile(uvad_ctx *, int sequences);
 int uvad_get_recurrent_tile(const uvad_ctx *);
+/* What mode 0 would launch for a batch of B sequences (4 or 16).  A sweep sharded over n GPUs that wants every utterance to
+ * get the same bits as the unsharded run pins all ranks to uvad_recurrent_tile_for(ctx, GLOBAL batch) (tools/run_cfg4.py
+ * --reproducible); left alone each rank picks the faster form for its own shard and results agree to rounding. */
+int uvad_recurrent_tile_for(const uvad_ctx *, int B);
 
 /* Do two HIP streams run concurrently?  HIP maps streams onto a small pool of hardware queues and two streams that share
  * a queue serialise, which silently defeats "two batches in flight" (ForwardPipeline).  The probe enqueues a 3 ms

@@ -135,7 +135,8 @@ def test_cfg4_large_batch_throughput_recurrence_and_shard_invariance():
     gain = 0.25 + 0.75 * torch.rand(B // 64, 1, 1, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
     pcm = (base.unsqueeze(0) * gain).reshape(B, S).contiguous()        # 4096 distinct utterances (64 signals x 64 gains)
     full, _ = rt.forward(pcm, want_probs=False)
-    assert rt.recurrent_tile() == 16, "B = 4096 bidirectional must select the 16-sequence recurrent kernel"
+    assert rt.recurrent_tile() == 16 == rt.recurrent_tile_for(B), "B = 4096 bidirectional must select the 16-sequence recurrent kernel"
+    assert rt.recurrent_tile_for(256) == 4 and rt.recurrent_tile_for(1024) == 4
     assert full.shape == (B, 1000) and torch.isfinite(full).all()
     # subset vs the CPU paths on identical features
     sub = [0, 1, 777, 2048, 4095]
@@ -163,7 +164,7 @@ def test_cfg4_large_batch_throughput_recurrence_and_shard_invariance():
             assert torch.equal(part, full[idx]), f"shard {r}/{n} differs from the unsharded batch"
             rt.set_recurrent_tile(0)
             auto, _ = rt.forward(pcm[idx].contiguous(), want_probs=False)
-            assert rt.recurrent_tile() == (16 if len(idx) >= 1024 else 4)
+            assert rt.recurrent_tile() == rt.recurrent_tile_for(len(idx))
             assert torch.equal(auto, part) if rt.recurrent_tile() == 16 else (auto - part).abs().max() < LOGIT_TOL
 
 

@@ -15,12 +15,16 @@ from uvad_amd.synth import seed_weights
 ap = argparse.ArgumentParser()
 ap.add_argument("--hours", type=float, default=10.0)
 ap.add_argument("--batch", type=int, default=4096, help="utterances per global batch (10 s each)")
+ap.add_argument("--reproducible", action="store_true",
+                help="pin every rank to the recurrent form the GLOBAL batch would use on one GPU: bit-identical logits for any number of GPUs")
 args = ap.parse_args()
 rank, local_rank, world = udist.init()
 dev = torch.device("cuda", local_rank); torch.cuda.set_device(dev)
 m = uvad_amd.PyanNet2(encoding_dim=64); m.build(); seed_weights(m, 1234, 4.0)
 m.attach_fbank(uvad_amd.FbankConfig(num_filters=64, window_type="hamming")); m = m.to(dev).eval()
 rt = m.runtime(dev)
+if args.reproducible:
+    rt.set_recurrent_tile(rt.recurrent_tile_for(args.batch))
 S = 160000
 n_utt = int(args.hours * 3600 / 10)
 n_batches = max(1, n_utt // args.batch)

@@ -444,6 +444,13 @@ void pack_whh16(const float *w_hh, int H, float *out) {
 // tile_mode 0: the form with the smaller estimated time.  One workgroup per CU at a time for both forms (registers), so a
 // launch takes ceil(workgroups / CUs) rounds; a round of the 16-sequence form costs REC16_ROUND_COST rounds of the
 // 4-sequence form (measured at B = 1024 ... 4096, profiles/README.md).  4 / 16 force either.  *tile_used reports the choice.
+int lstm_auto_tile(int tiles, int dirs, int H, int n_cu) {
+    if (H != 128) return 4;
+    const int ncu = n_cu > 0 ? n_cu : 256;
+    const long rounds4 = ((long)tiles * dirs + ncu - 1) / ncu, rounds16 = ((long)((tiles + 3) / 4) * dirs + ncu - 1) / ncu;
+    return (double)rounds16 * REC16_ROUND_COST < (double)rounds4 ? 16 : 4;
+}
+
 hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
     if (tile_used) *tile_used = 0;
     if (a.tiles <= 0 || a.T <= 0) return hipSuccess;
@@ -451,9 +458,7 @@ hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
     if (a.tile_mode == 16 && !can16) return hipErrorInvalidValue;
     const bool planes = a.Y == nullptr;
     if (planes && (!a.Yh || !a.Yl)) return hipErrorInvalidValue;
-    const int ncu = a.n_cu > 0 ? a.n_cu : 256;
-    const long rounds4 = ((long)a.tiles * a.dirs + ncu - 1) / ncu, rounds16 = ((long)((a.tiles + 3) / 4) * a.dirs + ncu - 1) / ncu;
-    const bool pick16 = (double)rounds16 * REC16_ROUND_COST < (double)rounds4;
+    const bool pick16 = lstm_auto_tile(a.tiles, a.dirs, a.H, a.n_cu) == 16;
     if (can16 && (a.tile_mode == 16 || (a.tile_mode == 0 && pick16))) {
         if (tile_used) *tile_used = 16;
         const dim3 grid16((a.tiles + 3) / 4, a.dirs);

@@ -877,6 +877,11 @@ int uvad_set_recurrent_tile(uvad_ctx *c, int sequences) {
 
 int uvad_get_recurrent_tile(const uvad_ctx *c) { return c ? c->rec_tile_used : UVAD_E_ARG; }
 
+int uvad_recurrent_tile_for(const uvad_ctx *c, int B) {
+    if (!c || !c->has_model || B <= 0) return UVAD_E_ARG;
+    return lstm_auto_tile((B + SEQ_TILE - 1) / SEQ_TILE, c->mc.bidirectional ? 2 : 1, c->mc.hidden, c->n_cu);
+}
+
 int uvad_streams_overlap(uvad_ctx *c, void *stream_a, void *stream_b) {
     if (!c) return UVAD_E_ARG;
     if (stream_a == stream_b) return 0;

@@ -94,6 +94,7 @@ struct LstmArgs {
     const float *h0, *c0; float *hN, *cN;
 };
 hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used = nullptr);
+int lstm_auto_tile(int tiles, int dirs, int H, int n_cu);   // what tile_mode 0 picks (4 or 16)
 // elements of the packed W_hh image for one direction
 size_t whh_packed_elems(int H);
 int lstm_waves(int H);   // waves per recurrent workgroup (8 at H = 128: two per SIMD)

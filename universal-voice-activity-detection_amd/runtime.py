@@ -271,6 +271,10 @@ class VadRuntime:
         """Sequences per recurrent workgroup: 0 (default) = chosen from the batch size, 4 = latency form, 16 = throughput form."""
         self._check(self.lib.uvad_set_recurrent_tile(self.ctx, int(sequences)))
 
+    def recurrent_tile_for(self, batch: int) -> int:
+        """What the default choice would launch for `batch` sequences (4 or 16)."""
+        return int(self.lib.uvad_recurrent_tile_for(self.ctx, int(batch)))
+
     def recurrent_tile(self) -> int:
         """What the most recent classify / forward launched (4 or 16)."""
         return int(self.lib.uvad_get_recurrent_tile(self.ctx))
