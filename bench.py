@@ -173,7 +173,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath) and B == B_PER_GPU:
             kk = json.load(open(tpath))["kernels"]
-            key = next((k for k in kk if k.startswith("lstm_rec_kernel" if kern.startswith("lstm") else "gemm_f16p_kernel grid=4096000")), None)
+            key = next((k for k in kk if k.startswith("lstm_rec_kernel" if kern.startswith("lstm") else "gemm_f16p_kernel<false> grid=8192000")), None)
             if key in kk:
                 traffic, traffic_src = kk[key]["hbm_MB_per_launch"] * 1e6, "profiles/" + name
                 break

@@ -49,18 +49,15 @@ typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
 constexpr int BM = PLANE_TILE, BN = 64;
-#ifndef UVAD_F16P_NKB
-#define UVAD_F16P_NKB 1
-#endif
 
 // LDS image of one 16-deep k-block (f16 elements): 128 rows of A hi, 128 of A lo, 64 rows each of W P0 / P1 / P2; a row is
 // 16 elements = two 16-byte chunks, chunk c of row r sits at slot c ^ ((r >> 3) & 1) (rows r and r + 8 share a bank line)
 constexpr int KB_AHI = 0, KB_ALO = BM * 16, KB_W0 = 2 * BM * 16, KB_W1 = KB_W0 + BN * 16, KB_W2 = KB_W1 + BN * 16, KB_ELEMS = KB_W2 + BN * 16;
 
-template <int NKB, bool OUT_PLANES>   // NKB: 16-deep k-blocks per pipeline stage (1: 14 KiB stages, 2: 28 KiB)
-__global__ __launch_bounds__(256, NKB == 1 ? 4 : 2) void gemm_f16p_kernel(GemmArgs a, int mt, int nt) {
-    constexpr int STAGE = NKB * KB_ELEMS;
-    constexpr int LDS_ELEMS = 2 * STAGE > BM * BN * 2 ? 2 * STAGE : BM * BN * 2;   // the f32 output tile of the blocked epilogue aliases the stages
+template <bool OUT_PLANES>
+__global__ __launch_bounds__(256, 4) void gemm_f16p_kernel(GemmArgs a, int mt, int nt) {
+    constexpr int STAGE = KB_ELEMS, NST = 2;   // two LDS stages of one 16-deep k-block each
+    constexpr int LDS_ELEMS = NST * STAGE > BM * BN * 2 ? NST * STAGE : BM * BN * 2;   // the f32 output tile of the blocked epilogue aliases the stages
     __shared__ __attribute__((aligned(16))) unsigned short lds[LDS_ELEMS];
 
     if (a.gate && (*a.gate != 0) != (a.gate_run_if_set != 0)) return;   // device-side kernel selection (see GemmArgs)
@@ -73,29 +70,27 @@ __global__ __launch_bounds__(256, NKB == 1 ? 4 : 2) void gemm_f16p_kernel(GemmAr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- DMA plan.  Per k-block: the A hi slab (256 chunks = one instruction of the whole workgroup), the A lo slab, the
-    //      W P0 slab (waves 0-1) + W P1 slab (waves 2-3), the W P2 slab (waves 0-1).  A lane always fetches the chunk that
-    //      belongs at its LDS slot (slot s of row r holds chunk s ^ ((r >> 3) & 1)): bases are wave-uniform, the lane offset
-    //      is one constant for A slabs and one for W slabs.
-    const int nkb = a.K / 16;                                   // k-blocks of the whole contraction
+    // ---- DMA plan.  Per k-block FOUR wave-instructions per wave:
+    //      a quarter of the A hi slab, a quarter of the A lo slab, a quarter of the W P0 slab (waves 0-1) or W P1 slab (waves 2-3),
+    //      and -- lanes 0-31 only -- a quarter of the W P2 slab.  A lane always fetches the chunk that belongs at its LDS slot
+    //      (slot s of row r holds chunk s ^ ((r >> 3) & 1)): bases are wave-uniform, lane offsets are constants.
+    const int nkb = a.K / 16;                                   // k-blocks of the whole contraction (K is a multiple of 32)
     const unsigned short *a_hi = a.Ah + (size_t)m_tile * nkb * (BM * 16);
     const unsigned short *a_lo = a.Al + (size_t)m_tile * nkb * (BM * 16);
     const size_t wplane = (size_t)((a.N + BN - 1) / BN) * nkb * (BN * 16);   // elements per W plane (N padded to whole 64-row tiles)
     const unsigned short *w_a = a.Wsplit16 + (wave < 2 ? 0 : wplane) + (size_t)n_tile * nkb * (BN * 16);   // P0 or P1
     const unsigned short *w_2 = a.Wsplit16 + 2 * wplane + (size_t)n_tile * nkb * (BN * 16);
-    const int ra = tid >> 1, rw = (tid & 127) >> 1;
+    const int ra = tid >> 1, rw = (tid & 127) >> 1, q2 = wave * 32 + (lane & 31), r2 = q2 >> 1;
     const unsigned off_a = (unsigned)((ra * 2 + ((tid & 1) ^ ((ra >> 3) & 1))) * 8);
     const unsigned off_w = (unsigned)((rw * 2 + ((tid & 1) ^ ((rw >> 3) & 1))) * 8);
-    auto issue = [&](int stage, int kb0) {
-#pragma unroll
-        for (int b = 0; b < NKB; ++b) {
-            unsigned short *img = lds + stage * STAGE + b * KB_ELEMS;
-            const size_t ka = (size_t)(kb0 + b) * (BM * 16), kw = (size_t)(kb0 + b) * (BN * 16);
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_hi + ka + off_a), (lptr_t)(img + KB_AHI + wave * 512), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_lo + ka + off_a), (lptr_t)(img + KB_ALO + wave * 512), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_a + kw + off_w), (lptr_t)(img + KB_W0 + wave * 512), 16, 0, 0);   // waves 2-3 land in KB_W1
-            if (wave < 2) __builtin_amdgcn_global_load_lds((gptr_t)(w_2 + kw + off_w), (lptr_t)(img + KB_W2 + wave * 512), 16, 0, 0);
-        }
+    const unsigned off_2 = (unsigned)((r2 * 2 + ((q2 & 1) ^ ((r2 >> 3) & 1))) * 8);
+    auto issue = [&](int stage, int kb) {
+        unsigned short *img = lds + stage * STAGE;
+        const size_t ka = (size_t)kb * (BM * 16), kw = (size_t)kb * (BN * 16);
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_hi + ka + off_a), (lptr_t)(img + KB_AHI + wave * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_lo + ka + off_a), (lptr_t)(img + KB_ALO + wave * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_a + kw + off_w), (lptr_t)(img + KB_W0 + wave * 512), 16, 0, 0);   // waves 2-3 land in KB_W1
+        if (lane < 32) __builtin_amdgcn_global_load_lds((gptr_t)(w_2 + kw + off_2), (lptr_t)(img + KB_W2 + wave * 256), 16, 0, 0);
     };
 
     f32x16 hi0, hi1, lo0, lo1;
@@ -109,36 +104,35 @@ __global__ __launch_bounds__(256, NKB == 1 ? 4 : 2) void gemm_f16p_kernel(GemmAr
     const int fa0 = arow0 * 16 + ((fh ^ ((arow0 >> 3) & 1)) * 8), fa1 = arow1 * 16 + ((fh ^ ((arow1 >> 3) & 1)) * 8);
     const int fw = wrow * 16 + ((fh ^ ((wrow >> 3) & 1)) * 8);
 
-    const int nk = nkb / NKB;   // K is padded to a multiple of 32 by the producers (zero columns)
+    // ---- k loop: plain double buffer, one barrier per k-block; the DMA of k-block kt + 1 is in flight during the MFMAs of kt.
+    //      (A 3- and a 4-stage ring with counted vmcnt waits and raw barriers measured the same 2.27 ms for the four projections:
+    //      with five workgroups per CU the k loop runs the f16 matrix pipe at ~65 %, it is not waiting for the DMA.)
     issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();   // (hipcc waits vmcnt(0) here) stage kt has landed for every wave; everyone is done reading stage kt-1
+    for (int kt = 0; kt < nkb; ++kt) {
+        __syncthreads();   // (hipcc waits vmcnt(0) here) k-block kt has landed for every wave; everyone is done reading k-block kt-1
 #ifndef UVAD_F16P_ABL_NODMA   // diagnostic builds (tools/stage_times.py --lib): outputs of ablated builds are meaningless
-        if (kt + 1 < nk) issue((kt + 1) & 1, (kt + 1) * NKB);
+        if (kt + 1 < nkb) issue((kt + 1) % NST, kt + 1);
 #endif
-#pragma unroll
-        for (int b = 0; b < NKB; ++b) {
-            const unsigned short *st = lds + (kt & 1) * STAGE + b * KB_ELEMS;
-            const f16x8 a0h = *reinterpret_cast<const f16x8 *>(st + KB_AHI + fa0);
-            const f16x8 a0l = *reinterpret_cast<const f16x8 *>(st + KB_ALO + fa0);
-            const f16x8 a1h = *reinterpret_cast<const f16x8 *>(st + KB_AHI + fa1);
-            const f16x8 a1l = *reinterpret_cast<const f16x8 *>(st + KB_ALO + fa1);
-            const f16x8 w0 = *reinterpret_cast<const f16x8 *>(st + KB_W0 + fw);
-            const f16x8 w1 = *reinterpret_cast<const f16x8 *>(st + KB_W1 + fw);
-            const f16x8 w2 = *reinterpret_cast<const f16x8 *>(st + KB_W2 + fw);
+        const unsigned short *st = lds + (kt % NST) * STAGE;
+        const f16x8 a0h = *reinterpret_cast<const f16x8 *>(st + KB_AHI + fa0);
+        const f16x8 a0l = *reinterpret_cast<const f16x8 *>(st + KB_ALO + fa0);
+        const f16x8 a1h = *reinterpret_cast<const f16x8 *>(st + KB_AHI + fa1);
+        const f16x8 a1l = *reinterpret_cast<const f16x8 *>(st + KB_ALO + fa1);
+        const f16x8 w0 = *reinterpret_cast<const f16x8 *>(st + KB_W0 + fw);
+        const f16x8 w1 = *reinterpret_cast<const f16x8 *>(st + KB_W1 + fw);
+        const f16x8 w2 = *reinterpret_cast<const f16x8 *>(st + KB_W2 + fw);
 #ifdef UVAD_F16P_ABL_NOMFMA
-            asm volatile("" ::"v"(a0h), "v"(a0l), "v"(a1h), "v"(a1l), "v"(w0), "v"(w1), "v"(w2));
-            continue;
+        asm volatile("" ::"v"(a0h), "v"(a0l), "v"(a1h), "v"(a1l), "v"(w0), "v"(w1), "v"(w2));
+        continue;
 #endif
-            lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w1, lo0, 0, 0, 0);
-            lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w1, lo1, 0, 0, 0);
-            lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, w0, lo0, 0, 0, 0);
-            lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, w0, lo1, 0, 0, 0);
-            lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w2, lo0, 0, 0, 0);
-            lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w2, lo1, 0, 0, 0);
-            hi0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w0, hi0, 0, 0, 0);
-            hi1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w0, hi1, 0, 0, 0);
-        }
+        lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w1, lo0, 0, 0, 0);
+        lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w1, lo1, 0, 0, 0);
+        lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, w0, lo0, 0, 0, 0);
+        lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, w0, lo1, 0, 0, 0);
+        lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w2, lo0, 0, 0, 0);
+        lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w2, lo1, 0, 0, 0);
+        hi0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w0, hi0, 0, 0, 0);
+        hi1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w0, hi1, 0, 0, 0);
     }
 
     // ---- epilogue: (hi + lo * 2^-11) * 2^-S + bias, activation.  C layout of the 32x32 MFMA: register r of lane (fr, fh) =
@@ -287,9 +281,9 @@ hipError_t launch_gemm_f16p(const GemmArgs &a, hipStream_t s) {
     const int mt = (a.M + BM - 1) / BM, nt = ((a.out_planes ? a.ldc : a.N) + BN - 1) / BN;
     const int grid = ((mt + 7) / 8) * 8 * nt;
     if (a.out_planes)
-        hipLaunchKernelGGL((gemm_f16p_kernel<UVAD_F16P_NKB, true>), dim3(grid), dim3(256), 0, s, a, mt, nt);
+        hipLaunchKernelGGL((gemm_f16p_kernel<true>), dim3(grid), dim3(256), 0, s, a, mt, nt);
     else
-        hipLaunchKernelGGL((gemm_f16p_kernel<UVAD_F16P_NKB, false>), dim3(grid), dim3(256), 0, s, a, mt, nt);
+        hipLaunchKernelGGL((gemm_f16p_kernel<false>), dim3(grid), dim3(256), 0, s, a, mt, nt);
     return hipGetLastError();
 }
 
