@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU (default = BASELINE cfg 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=3, help="steps in flight (1 = strictly sequential submission, 3 = default)")
+    ap.add_argument("--rec-tile", type=int, default=0, choices=[0, 4, 16],
+                    help="recurrent form of the in-flight contexts: 0 = the library's per-call choice, 4 = latency form, 16 = throughput form")
     ap.add_argument("--no-sequential", action="store_true", help="skip the extra strictly sequential measurement")
     ap.add_argument("--no-sincnet", action="store_true", help="skip the extra PyanNet (SincNet front end) measurement")
     ap.add_argument("--scatter", action="store_true",
@@ -89,7 +91,7 @@ def main():
     # order of INDEPENDENT steps changes: while one step sits in its latency-bound recurrence (128 of the 256 CUs at
     # B=256) the other step's feature kernel and projections run on the idle CUs.  --in-flight 1 = strictly sequential.
     n_fly = max(1, min(args.in_flight, 8))
-    pipe = uvad_amd.ForwardPipeline(model, dev, depth=n_fly)
+    pipe = uvad_amd.ForwardPipeline(model, dev, depth=n_fly, recurrent_tile=args.rec_tile)
     rts = pipe.runtimes
     rt = rts[0]
     pcm = synth_pcm_device(B, S, seed=42, device=dev, first=rank * B)   # disjoint utterance ids per rank
@@ -196,6 +198,7 @@ def main():
         "classifier_f32_equivalent_TFLOPs": frames_step * (proj_f + rec_f + head_f) / (elapsed / args.steps) / 1e12,
     }
     out["config"]["steps_in_flight"] = n_fly
+    out["config"]["recurrent_tile"] = rts[0].recurrent_tile()
     out["stages_note"] = ("per-stage HIP-event times of one step, measured inside the timed region on that step's own stream; with several steps "
                           "in flight the stages of different steps overlap (and slow each other down), so they do not add up to ms_per_step")
 

@@ -10,6 +10,7 @@ ap.add_argument("--lib", default=None)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--mode", default="f16p")
+ap.add_argument("--tile", type=int, default=0, help="recurrent form: 0 = by estimated time, 4, 16")
 args = ap.parse_args()
 import uvad_amd
 from uvad_amd import _lib
@@ -21,6 +22,7 @@ m = uvad_amd.PyanNet2(encoding_dim=64); m.build(); seed_weights(m, 1234, 4.0)
 m.attach_fbank(uvad_amd.FbankConfig(num_filters=64, window_type="hamming")); m = m.to(dev).eval()
 rt = m.runtime(dev)
 rt.set_gemm_mode(args.mode)
+rt.set_recurrent_tile(args.tile)
 pcm = synth_pcm_device(args.batch, 160000, seed=42, device=dev)
 for _ in range(3):
     rt.forward(pcm, want_probs=False)
@@ -31,4 +33,4 @@ for _ in range(args.reps):
     rt.forward(pcm, want_probs=False)
     for k, v in rt.timing_ms().items():
         acc[k] = acc.get(k, 0.0) + v / args.reps
-print(json.dumps({"lib": args.lib or "default", "mode": args.mode, "batch": args.batch, "ms": {k: round(v, 4) for k, v in acc.items()}}))
+print(json.dumps({"lib": args.lib or "default", "mode": args.mode, "batch": args.batch, "tile": rt.recurrent_tile(), "ms": {k: round(v, 4) for k, v in acc.items()}}))

@@ -282,24 +282,31 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------
-// Throughput variant for large batches (H = 128): 16 sequences per workgroup on v_mfma_f32_16x16x4_f32.
-//
-// When tiles*dirs exceeds the CU count the recurrence is no longer latency- but throughput-bound, and
-// the 2-pass 4x4x1 MFMA is the wrong instruction: it holds the vector issue port for its whole 8
-// cycles, so the cell updates are serialised behind the chains.  The 16x16x4 form does
-// the same MACs per cycle but issues once per 32 cycles, leaving 24 issue slots per MFMA to the VALU /
-// LDS work of both waves of the SIMD.  It needs N = 16 columns = 16 sequences per workgroup:
-//   A (16 rows x 4 k)  = W_hh rows of 4 units x 4 gates,   k-step ks covers k = 32*kk + ks (kk = lane>>4)
-//   B (4 k x 16 seqs)  = h_{t-1},  D: lane (q = lane>>4, j = lane&15) holds gates i,f,g,o (regs 0..3) of unit
-//   16*wave + 4*rb + q for sequence j  -> the cell update is lane-local again.
-// 8 waves x (4 row blocks x 32 k-steps) = 1024 MFMAs of 32 cycles per step and workgroup; W_hh stays in 128
-// AGPRs per lane.  Rows keep the SEQ_TILE = 4 layout (a workgroup owns 4 consecutive tiles), so GEMMs and
-// the classifier are unchanged.  No state carry / chunking (the callers that need those run small batches).
-template <int H, bool PLANES>
-__global__ __launch_bounds__(512) void lstm_rec16_kernel(LstmArgs a) {
-    static_assert(H == 128, "written for H = 128");
-    constexpr int NS = 16, RB = 4, KS = H / 4, HSK = 36, PD16 = 2;
-    __shared__ __attribute__((aligned(16))) float hbuf[2][4][NS][HSK];   // [buffer][kk][sequence][32 (+4 pad)]
+// Throughput form (H = 128): 16 sequences per workgroup, W_hh * h on the f16 matrix cores with the SAME operand split as
+// gemm_f16p.hip -- W_hh scaled by a power of two and split into three f16 planes that reproduce it exactly (a rounded
+// static weight would be a different network), h_t split into two f16 planes (22 bits, noise) -- four
+// v_mfma_f32_16x16x32_f16 products per term set in two f32 accumulators:
+//     hi += P0*h1;   lo += P1*h1 + P0*h2 + P2*h1;   W_hh*h = (hi + lo * 2^-11) * 2^-S
+// 64 MFMAs of 16 cycles per wave and step instead of the 128 x 32 cycles of the f32 form (v_mfma_f32_16x16x4_f32): the
+// matrix pipe stops being the bound and the cell updates (4 per lane and step) run in the issue slots the MFMAs leave free.
+//   A (16 rows x 32 k) = W_hh rows of 4 units x 4 gates: lane (r = lane & 15, kq = lane >> 4) holds k = 32 ks + 8 kq .. + 7
+//   B (32 k x 16 seqs) = h_{t-1}: lane (j = lane & 15, kq) holds the same 8 k of sequence j
+//   D: lane (q = lane >> 4, j) holds gates i,f,g,o (regs 0..3) of unit 16 wave + 4 rb + q for sequence j -> lane-local cell update
+// W_hh residency: P0 and P1 of a wave's 64 rows are 128 AGPRs per lane (as the f32 image was); P2 (128 KiB per direction)
+// does not fit beside them and lives in LDS, 16 KiB per wave, read as 16 conflict-free ds_read_b128 per step.
+// h_t is exchanged through a double-buffered LDS image of its two f16 planes ([plane][sequence][128 + 8 pad]: rows 272 bytes
+// apart, so the 16 sequence rows of a B-fragment read fall on disjoint banks).
+constexpr int R16_HP = 136;                          // f16 elements per h row in LDS (128 + pad)
+constexpr int R16_P2_ELEMS = 8 * 16 * 64 * 8;        // P2 image of one direction
+constexpr int R16_HB_ELEMS = 2 * 2 * 16 * R16_HP;    // [buffer][plane][sequence][R16_HP]
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+template <bool PLANES>
+__global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
+    constexpr int H = 128, RB = 4, KST = 4, PD16 = 1;   // the gates of a row block are re-requested for the next step as soon as this step has consumed them
+    extern __shared__ __attribute__((aligned(16))) unsigned short sm16[];
+    unsigned short *p2 = sm16, *hb = sm16 + R16_P2_ELEMS;
 
     const int tile16 = blockIdx.x, dir = blockIdx.y;
     const bool reverse = dir == 1;
@@ -307,14 +314,19 @@ __global__ __launch_bounds__(512) void lstm_rec16_kernel(LstmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, q = lane >> 4;
 
-    float w[RB * KS];
+    // ---- resident P0 / P1: register r = ((plane * 16 + rb * 4 + ks) * 4 + v) holds elements 2v, 2v+1 of that fragment
+    u32x4 w[32];   // fragment (plane, rb, ks) = w[plane * 16 + rb * 4 + ks]: one aligned 4-register tuple each
     {
-        const float4 *wp = reinterpret_cast<const float4 *>(a.Whh_packed16 + (size_t)dir * 4 * H * H);
+        const u32x4 *wp = reinterpret_cast<const u32x4 *>(a.Whh16h_regs + (size_t)dir * (8 * 128 * 64));
 #pragma unroll
-        for (int i = 0; i < RB * KS / 4; ++i) {
-            const float4 v = wp[(size_t)(wave * (RB * KS / 4) + i) * 64 + lane];
-            w[4 * i + 0] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
-        }
+        for (int i = 0; i < 32; ++i) w[i] = wp[(size_t)(wave * 32 + i) * 64 + lane];
+    }
+    // ---- P2 image of this direction -> LDS (128 KiB, once), h buffers zeroed (h_{-1} = 0)
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.Whh16h_p2 + (size_t)dir * R16_P2_ELEMS);
+        uint4 *dst = reinterpret_cast<uint4 *>(p2);
+        for (int i = threadIdx.x; i < R16_P2_ELEMS / 8; i += 512) dst[i] = src[i];
+        for (int i = threadIdx.x; i < R16_HB_ELEMS / 2; i += 512) reinterpret_cast<unsigned *>(hb)[i] = 0u;
     }
     // this lane's sequence: tile (of 4) and row offset; lanes of missing tiles in the last workgroup are clamped
     // for loads and masked for stores
@@ -323,28 +335,53 @@ __global__ __launch_bounds__(512) void lstm_rec16_kernel(LstmArgs a) {
     const int t4c = live ? t4 : a.tiles - 1;
     const size_t row0 = (size_t)t4c * a.T * SEQ_TILE + (j & 3);
     const int ubase = wave * 16 + q;   // unit of row block rb: ubase + 4*rb
-    const int gcol = dir * 4 * H + ubase * 4;   // G is tile-blocked (g_index); row block rb is 16 columns further
+    // Blocked layouts (g_index / plane_index): the wave's 64 gate columns are one 64-column tile of G and its 16 units one
+    // 16-column block of Y, so row block rb is simply 16 floats (G) / 4 elements (Y) further
+    const size_t g_wave = (size_t)(dir * 8 + wave) * (128 * 64) + 4 * q, g_tile = (size_t)(a.ldg / 64) * (128 * 64);
+    const size_t y_tile = (size_t)(a.ldy / 16) * (PLANE_TILE * 16);
     const size_t ycol = (size_t)dir * H + ubase;
+    auto g_ptr = [&](int t) {
+        const size_t R = row0 + (size_t)t * SEQ_TILE;
+        return a.G + (R >> 7) * g_tile + g_wave + (R & 127) * 64;
+    };
+    const float wscale = a.whh16h_scale[dir];
 
     float c[RB];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        c[rb] = 0.0f;
-        const int u = ubase + 4 * rb;
-        hbuf[0][u >> 5][j][u & 31] = 0.0f;
-    }
-    __syncthreads();
-
+    for (int rb = 0; rb < RB; ++rb) c[rb] = 0.0f;
     f32x4 gq[PD16][RB];
 #pragma unroll
     for (int p = 0; p < PD16; ++p) {
         const int sp = p < a.T ? p : a.T - 1;
         const int t = reverse ? a.T - 1 - sp : sp;
+        const float *gp = g_ptr(t);
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-            gq[p][rb] = *reinterpret_cast<const f32x4 *>(a.G + g_index(row0 + (size_t)t * SEQ_TILE, gcol + 16 * rb, a.ldg));
+        for (int rb = 0; rb < RB; ++rb) gq[p][rb] = *reinterpret_cast<const f32x4 *>(gp + 16 * rb);
     }
+    __syncthreads();
 
+    // Cooperative store of h_t as the two K-blocked f16 planes: the whole workgroup's output of a step is 8 KiB (2 planes x 16
+    // sequences x 128 units), laid out in HBM as 64 runs of 128 bytes (4 sequence rows x 16 units); after the barrier it sits
+    // complete in the LDS image the next step reads its B fragments from, and every thread moves ONE 16-byte piece of it
+    // (per-lane 2-byte stores straight from the cell update cost 37 % of the kernel).
+    auto coop_store = [&](const unsigned short *himg, int t) {
+        if constexpr (PLANES) {
+            // thread -> (plane, tile of 4 sequences, 16-unit block, row in tile, 16-byte half); recomputed every step from an
+            // opaque copy of the thread id so that none of it occupies registers across the MFMA section
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int cp = tid >> 8, ctt = (tid >> 6) & 3, ckb = (tid >> 3) & 7, cjb = (tid >> 1) & 3, chh = tid & 1;
+            const int ct4 = tile16 * 4 + ctt;
+            const bool clive = ct4 < a.tiles;
+            const size_t R = (size_t)(clive ? ct4 : a.tiles - 1) * a.T * SEQ_TILE + cjb + (size_t)t * SEQ_TILE;
+            const uint4 v = *reinterpret_cast<const uint4 *>(himg + cp * (16 * R16_HP) + (ctt * 4 + cjb) * R16_HP + ckb * 16 + chh * 8);
+            unsigned short *plane = cp ? a.Yl : a.Yh;
+            if (clive) *reinterpret_cast<uint4 *>(plane + (R >> 7) * y_tile + (size_t)(dir * 8 + ckb) * (PLANE_TILE * 16) + chh * 8 + (R & 127) * 16) = v;
+        }
+    };
+
+    const unsigned short *p2w = p2 + (size_t)(wave * 16) * 512 + lane * 8;   // fragment (rb, ks) at + (rb*4 + ks) * 512
+    const int hfrag = j * R16_HP + 8 * q;                                   // + 32 ks inside a plane
     for (int s0 = 0; s0 < a.T; s0 += PD16) {
 #pragma unroll
       for (int u2 = 0; u2 < PD16; ++u2) {
@@ -352,58 +389,71 @@ __global__ __launch_bounds__(512) void lstm_rec16_kernel(LstmArgs a) {
         if (s >= a.T) break;   // wave-uniform
         const int t = reverse ? a.T - 1 - s : s;
 #pragma unroll
-        for (int k = 0; k < RB * KS; ++k) asm volatile("" : "+a"(w[k]));   // W_hh stays in AGPRs (constraint only)
+        for (int k = 0; k < 32; ++k) asm volatile("" : "+a"(w[k]));   // P0 / P1 stay in AGPRs (constraint only)
 
-        // B operands: h_{s-1}[seq j][32*q + ks], ks = 0..31, as 8 x 16-byte reads
-        float4 hv[KS / 4];
-        const float *hb = &hbuf[s & 1][q][j][0];
+        const int spn = s + 1 < a.T ? s + 1 : a.T - 1;
+        const float *gnext = g_ptr(reverse ? a.T - 1 - spn : spn);
+        const unsigned short *hcur = hb + (s & 1) * (2 * 16 * R16_HP);
+        unsigned short *hnxt = hb + ((s + 1) & 1) * (2 * 16 * R16_HP);
+        f16x8 h1[KST], h2[KST];
 #pragma unroll
-        for (int i = 0; i < KS / 4; ++i) hv[i] = *reinterpret_cast<const float4 *>(hb + 4 * i);
-
-        // k-major over four independent accumulators (row blocks).  A variant with the row blocks one after the other and the
-        // cell update of block rb staged between the MFMA groups of block rb + 1 measured the same 5.7 us per step at
-        // B = 4096 (the kernel is bound by the f32 matrix pipe, 76 % busy), so the simple form stays.
-        f32x4 acc[RB];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) acc[rb] = gq[u2][rb];
-        {   // refill this ring slot with the gates of step min(s + PD16, T - 1)
-            const int sp = s + PD16 < a.T ? s + PD16 : a.T - 1;
-            const int tp = reverse ? a.T - 1 - sp : sp;
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-                gq[u2][rb] = *reinterpret_cast<const f32x4 *>(a.G + g_index(row0 + (size_t)tp * SEQ_TILE, gcol + 16 * rb, a.ldg));
-        }
-#pragma unroll
-        for (int i = 0; i < KS / 4; ++i) {
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[rb * KS + 4 * i + 0], hv[i].x, acc[rb], 0, 0, 0);
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[rb * KS + 4 * i + 1], hv[i].y, acc[rb], 0, 0, 0);
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[rb * KS + 4 * i + 2], hv[i].z, acc[rb], 0, 0, 0);
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[rb * KS + 4 * i + 3], hv[i].w, acc[rb], 0, 0, 0);
+        for (int ks = 0; ks < KST; ++ks) {
+            h1[ks] = *reinterpret_cast<const f16x8 *>(hcur + hfrag + 32 * ks);
+            h2[ks] = *reinterpret_cast<const f16x8 *>(hcur + 16 * R16_HP + hfrag + 32 * ks);
         }
         const size_t yrow = row0 + (size_t)t * SEQ_TILE;
+        // Row blocks one after the other (16 MFMAs each); the P2 fragment of MFMA group f + 1 is requested from LDS before group f.
+        // The kernel is bound by vector-instruction issue (~290 per wave and step: four cell updates per lane), not by the matrix
+        // pipe (40 % busy), so scheduling is left to the compiler: staging the cell update of row block rb between the MFMA
+        // groups of rb + 1 behind sched_barriers measured 10 % slower, a forced [4 MFMA, 1 LDS read] cadence 3 % slower.
         float hnew[RB];
+        f16x8 w2n = *reinterpret_cast<const f16x8 *>(p2w);
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) hnew[rb] = lstm_cell(acc[rb], c[rb]);
+        for (int rb = 0; rb < RB; ++rb) {
+            f32x4 hi = {0.f, 0.f, 0.f, 0.f}, lo = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) {
+                const int f = rb * 4 + ks;
+                const f16x8 w2 = w2n;
+                if (f + 1 < 16) w2n = *reinterpret_cast<const f16x8 *>(p2w + (f + 1) * 512);
+                const f16x8 w0 = __builtin_bit_cast(f16x8, w[f]);
+                const f16x8 w1 = __builtin_bit_cast(f16x8, w[16 + f]);
+#ifdef UVAD_R16_NOMFMA
+                asm volatile("" ::"v"(w0), "v"(w1), "v"(w2), "v"(h1[ks]), "v"(h2[ks]));
+                lo[0] += (float)w2[0];
+#else
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, h1[ks], lo, 0, 0, 0);
+                hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, h1[ks], hi, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, h2[ks], lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, h1[ks], lo, 0, 0, 0);
+#endif
+            }
+            f32x4 g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = __builtin_fmaf(__builtin_fmaf(lo[e], 0.00048828125f, hi[e]), wscale, gq[u2][rb][e]);
+#ifndef UVAD_R16_NOGLOAD
+            gq[u2][rb] = *reinterpret_cast<const f32x4 *>(gnext + 16 * rb);   // next step's gates of this row block: a whole step to arrive
+#endif
+            hnew[rb] = lstm_cell(g, c[rb]);
+        }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const int u = ubase + 4 * rb;
-            hbuf[(s + 1) & 1][u >> 5][j][u & 31] = hnew[rb];
-            if (live) {
-                if constexpr (PLANES) {
-                    const size_t yo = plane_index(yrow, (int)ycol + 4 * rb, a.ldy);
-                    store_planes(a.Yh + yo, a.Yl + yo, hnew[rb]);
-                } else {
-                    a.Y[yrow * a.ldy + ycol + 4 * rb] = hnew[rb];
-                }
+            const _Float16 hh = (_Float16)hnew[rb];
+            const _Float16 hl = (_Float16)((hnew[rb] - (float)hh) * 2048.0f);
+            hnxt[j * R16_HP + u] = __builtin_bit_cast(unsigned short, hh);
+            hnxt[16 * R16_HP + j * R16_HP + u] = __builtin_bit_cast(unsigned short, hl);
+            if constexpr (!PLANES) {
+                if (live) a.Y[yrow * a.ldy + ycol + 4 * rb] = hnew[rb];   // exact-f32 output: per lane (the planes in LDS hold 22 bits)
             }
         }
+        // h of the PREVIOUS step (complete in LDS since the last barrier, not overwritten before the next one) goes out now,
+        // when the fragment registers of this step are dead
+        if (s > 0) coop_store(hcur, reverse ? t + 1 : t - 1);
         __syncthreads();
       }
     }
+    if (a.T > 0) coop_store(hb + (a.T & 1) * (2 * 16 * R16_HP), reverse ? 0 : a.T - 1);
 }
 
 }  // namespace
@@ -411,6 +461,8 @@ __global__ __launch_bounds__(512) void lstm_rec16_kernel(LstmArgs a) {
 constexpr double REC16_ROUND_COST = 3.0;   // time of one round of the 16-sequence form / one round of the 4-sequence form
 
 size_t whh_packed_elems(int H) { return (size_t)4 * H * H; }
+size_t whh16h_regs_elems() { return (size_t)8 * 128 * 64; }        // u32 per direction
+size_t whh16h_p2_elems() { return (size_t)R16_P2_ELEMS; }          // f16 per direction
 
 int lstm_waves(int H) { return H == 128 ? 8 : 4; }
 
@@ -426,24 +478,63 @@ void pack_whh(const float *w_hh, int H, float *out) {
                 }
 }
 
-// register image of lstm_rec16_kernel: [wave 8][rb 4][ks 32 (as 8 float4)][lane 64]
-void pack_whh16(const float *w_hh, int H, float *out) {
-    const int KS = H / 4;
+// Images of lstm_rec16h_kernel for one direction, from torch w_hh [4H][H] (rows i,f,g,o), H = 128:
+//   regs: P0 / P1 fragments as [wave 8][i 32][lane 64][4 x u32]; the lane's register r = 4 i + e = ((plane * 16 + rb * 4 + ks) * 4 + v)
+//         holds elements 2v, 2v+1 (low, high half) of fragment (plane, rb, ks): row lane & 15 -> unit 16 wave + 4 rb + (row >> 2),
+//         gate row & 3; k = 32 ks + 8 (lane >> 4) + element
+//   p2:   P2 fragments as [wave 8][rb * 4 + ks 16][lane 64][8 f16]
+//   *wscale = 2^-S, the power-of-two scale that put max|w| into [2^13, 2^14) before the exact three-way split (gemm_f16p.hip)
+bool pack_whh16h(const float *w_hh, unsigned *regs, unsigned short *p2, float *wscale) {
+    const int H = 128;
+    float amax = 0.0f;
+    bool finite = true;
+    for (size_t i = 0; i < (size_t)4 * H * H; ++i) {
+        const float v = __builtin_fabsf(w_hh[i]);
+        if (!(v <= 3.0e38f)) finite = false;
+        if (v > amax) amax = v;
+    }
+    int S = 0;
+    if (finite && amax > 0.0f) {
+        int e;
+        (void)__builtin_frexpf(amax, &e);
+        S = 14 - e;
+        if (S > 100) S = 100;
+        if (S < -100) S = -100;
+    }
+    const float up = __builtin_ldexpf(1.0f, S);
+    *wscale = __builtin_ldexpf(1.0f, -S);
+    auto piece = [&](int gate, int unit, int k, int plane) -> unsigned short {
+        const float ws = finite ? w_hh[(size_t)(gate * H + unit) * H + k] * up : 0.0f;
+        const _Float16 p0 = (_Float16)ws;
+        const float t2 = (ws - (float)p0) * 2048.0f;
+        const _Float16 p1 = (_Float16)t2;
+        const _Float16 p2v = (_Float16)(t2 - (float)p1);
+        const _Float16 v = plane == 0 ? p0 : plane == 1 ? p1 : p2v;
+        unsigned short b;
+        __builtin_memcpy(&b, &v, 2);
+        return b;
+    };
     for (int wave = 0; wave < 8; ++wave)
-        for (int rb = 0; rb < 4; ++rb)
-            for (int ks = 0; ks < KS; ++ks)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int i = lane & 15, kk = lane >> 4;
-                    const int gate = i & 3, unit = wave * 16 + 4 * rb + (i >> 2);
-                    const int idx = rb * KS + ks;   // element index in the lane's w[] array
-                    out[((size_t)(wave * (4 * KS / 4) + idx / 4) * 64 + lane) * 4 + (idx & 3)] =
-                        w_hh[(size_t)(gate * H + unit) * H + 32 * kk + ks];
+        for (int lane = 0; lane < 64; ++lane) {
+            const int row = lane & 15, kq = lane >> 4;
+            for (int rb = 0; rb < 4; ++rb)
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int unit = 16 * wave + 4 * rb + (row >> 2), gate = row & 3, f = rb * 4 + ks;
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = 32 * ks + 8 * kq + e;
+                        for (int plane = 0; plane < 2; ++plane) {
+                            const int r = (plane * 16 + f) * 4 + (e >> 1);
+                            unsigned &dst = regs[((size_t)(wave * 32 + (r >> 2)) * 64 + lane) * 4 + (r & 3)];
+                            const unsigned bits = piece(gate, unit, k, plane);
+                            dst = (e & 1) ? ((dst & 0x0000ffffu) | (bits << 16)) : ((dst & 0xffff0000u) | bits);
+                        }
+                        p2[((size_t)(wave * 16 + f) * 64 + lane) * 8 + e] = piece(gate, unit, k, 2);
+                    }
                 }
+        }
+    return finite;
 }
 
-// tile_mode 0: the form with the smaller estimated time.  One workgroup per CU at a time for both forms (registers), so a
-// launch takes ceil(workgroups / CUs) rounds; a round of the 16-sequence form costs REC16_ROUND_COST rounds of the
-// 4-sequence form (measured at B = 1024 ... 4096, profiles/README.md).  4 / 16 force either.  *tile_used reports the choice.
 int lstm_auto_tile(int tiles, int dirs, int H, int n_cu) {
     if (H != 128) return 4;
     const int ncu = n_cu > 0 ? n_cu : 256;
@@ -454,7 +545,7 @@ int lstm_auto_tile(int tiles, int dirs, int H, int n_cu) {
 hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
     if (tile_used) *tile_used = 0;
     if (a.tiles <= 0 || a.T <= 0) return hipSuccess;
-    const bool can16 = a.H == 128 && a.Whh_packed16 && !a.h0 && !a.hN;
+    const bool can16 = a.H == 128 && a.Whh16h_regs && a.Whh16h_p2 && a.whh16h_scale && !a.h0 && !a.hN;
     if (a.tile_mode == 16 && !can16) return hipErrorInvalidValue;
     const bool planes = a.Y == nullptr;
     if (planes && (!a.Yh || !a.Yl)) return hipErrorInvalidValue;
@@ -462,8 +553,16 @@ hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
     if (can16 && (a.tile_mode == 16 || (a.tile_mode == 0 && pick16))) {
         if (tile_used) *tile_used = 16;
         const dim3 grid16((a.tiles + 3) / 4, a.dirs);
-        if (planes) hipLaunchKernelGGL((lstm_rec16_kernel<128, true>), grid16, dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((lstm_rec16_kernel<128, false>), grid16, dim3(512), 0, s, a);
+        const size_t lds = (size_t)(R16_P2_ELEMS + R16_HB_ELEMS) * sizeof(unsigned short);   // 145 KiB: one workgroup per CU
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[planes]) {
+            const hipError_t e = planes ? hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_rec16h_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                        : hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_rec16h_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_set[planes] = true;
+        }
+        if (planes) hipLaunchKernelGGL((lstm_rec16h_kernel<true>), grid16, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((lstm_rec16h_kernel<false>), grid16, dim3(512), lds, s, a);
         return hipGetLastError();
     }
     if (tile_used) *tile_used = 4;

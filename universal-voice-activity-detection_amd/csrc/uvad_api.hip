@@ -26,7 +26,10 @@ struct LayerDev {
     float w_ih_scale = 1.0f;
     float *bias = nullptr;   // [dirs*4H] b_ih + b_hh, same permutation
     float *w_hh = nullptr;   // [dirs][packed register image]
-    float *w_hh16 = nullptr; // [dirs][register image of the 16-sequence kernel] (H = 128)
+    unsigned *w_hh16_regs = nullptr;        // 16-sequence kernel (H = 128): [dirs][P0 / P1 register image]
+    unsigned short *w_hh16_p2 = nullptr;    // [dirs][P2 LDS image]
+    float *w_hh16_scale = nullptr;          // [dirs] 2^-S
+    bool w_hh16_ok = false;
     int in = 0;
 };
 
@@ -328,7 +331,10 @@ int uvad_finalize(uvad_ctx *c) {
         const int in = k == 0 ? m.in_dim : H * D;
         const int inp = gemm_padded_k(in);   // rows zero-padded to the GEMM's K-step
         std::vector<float> wp((size_t)D * 4 * H * inp, 0.0f), bp((size_t)D * 4 * H), hh((size_t)D * whh_packed_elems(H));
-        std::vector<float> hh16((size_t)D * whh_packed_elems(H));
+        std::vector<unsigned> hh16r(H == 128 ? (size_t)D * whh16h_regs_elems() : 0, 0u);
+        std::vector<unsigned short> hh16p(H == 128 ? (size_t)D * whh16h_p2_elems() : 0, 0);
+        std::vector<float> hh16s(D, 1.0f);
+        bool hh16ok = H == 128;
         for (int d = 0; d < D; ++d) {
             const std::string suf = "_l" + std::to_string(k) + (d ? "_reverse" : "");
             const HostTensor *wih = get("lstm.weight_ih" + suf), *whh = get("lstm.weight_hh" + suf);
@@ -345,7 +351,8 @@ int uvad_finalize(uvad_ctx *c) {
                     bp[dst] = bih->data[src] + bhh->data[src];
                 }
             pack_whh(whh->data.data(), H, &hh[(size_t)d * whh_packed_elems(H)]);
-            if (H == 128) pack_whh16(whh->data.data(), H, &hh16[(size_t)d * whh_packed_elems(H)]);
+            if (H == 128 && !pack_whh16h(whh->data.data(), &hh16r[(size_t)d * whh16h_regs_elems()], &hh16p[(size_t)d * whh16h_p2_elems()], &hh16s[d]))
+                hh16ok = false;
         }
         LayerDev &L = c->layers[k];
         L.in = in;
@@ -358,7 +365,12 @@ int uvad_finalize(uvad_ctx *c) {
         }
         if ((r = dev_upload(c, bp.data(), bp.size(), &L.bias, true))) return r;
         if ((r = dev_upload(c, hh.data(), hh.size(), &L.w_hh, true))) return r;
-        if (H == 128 && (r = dev_upload(c, hh16.data(), hh16.size(), &L.w_hh16, true))) return r;
+        if (H == 128) {
+            if ((r = dev_upload(c, hh16r.data(), hh16r.size(), &L.w_hh16_regs, true))) return r;
+            if ((r = dev_upload(c, hh16p.data(), hh16p.size(), &L.w_hh16_p2, true))) return r;
+            if ((r = dev_upload(c, hh16s.data(), hh16s.size(), &L.w_hh16_scale, true))) return r;
+        }
+        L.w_hh16_ok = hh16ok;
     }
     c->lin_w.assign(m.lin_layers, nullptr);
     c->lin_b.assign(m.lin_layers, nullptr);
@@ -631,7 +643,8 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         }
         if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k + 1], s));
         LstmArgs r{};
-        r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.Whh_packed16 = L.w_hh16; r.ldy = w.Wd;
+        r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.ldy = w.Wd;
+        if (L.w_hh16_ok) { r.Whh16h_regs = L.w_hh16_regs; r.Whh16h_p2 = L.w_hh16_p2; r.whh16h_scale = L.w_hh16_scale; }
         if (y_planes(k)) { r.Yh = hi_of(w.off_Y[k & 1]); r.Yl = lo_of(w.off_Y[k & 1], w.Wd); }
         else r.Y = Yf(k & 1);
         r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D; r.tile_mode = ss ? 4 : c->rec_tile_mode; r.n_cu = c->n_cu;

@@ -84,7 +84,8 @@ hipError_t launch_split_features(const float *x, int B, int T, int F, int Fp, in
 struct LstmArgs {
     const float *G; int ldg;
     const float *Whh_packed;     // per dir: register image, see pack_whh()
-    const float *Whh_packed16;   // per dir: register image of the 16-sequence kernel (pack_whh16), H = 128 only
+    // 16-sequence form (H = 128 only, pack_whh16h): per dir the P0 / P1 register image, the P2 LDS image, and 2^-S
+    const unsigned *Whh16h_regs; const unsigned short *Whh16h_p2; const float *whh16h_scale;
     float *Y; int ldy;           // f32 output (exact-f32 GEMM mode), or
     unsigned short *Yh, *Yl;     // the two K-blocked f16 planes (ldy columns) h ~= hi + lo * 2^-11 the f16p GEMM of the next layer reads (Y == nullptr)
     int tiles, T, H, dirs;
@@ -100,7 +101,9 @@ size_t whh_packed_elems(int H);
 int lstm_waves(int H);   // waves per recurrent workgroup (8 at H = 128: two per SIMD)
 // host-side packer: torch w_hh [4H][H] (rows i,f,g,o) -> register image
 void pack_whh(const float *w_hh, int H, float *out);
-void pack_whh16(const float *w_hh, int H, float *out);
+size_t whh16h_regs_elems();
+size_t whh16h_p2_elems();
+bool pack_whh16h(const float *w_hh, unsigned *regs, unsigned short *p2, float *wscale);   // false: a weight is non-finite
 
 // ---- head.hip -----------------------------------------------------------------------------
 // logit = Z[m][:K] . w + b ; prob = sigmoid(logit); written at canonical [b][t] (b < B only).

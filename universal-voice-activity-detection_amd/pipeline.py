@@ -34,8 +34,11 @@ class Pending:
 class ForwardPipeline:
     MAX_STREAM_TRIES = 16
 
-    def __init__(self, model, device, depth: int = 2):
-        """model: a built uvad_amd.PyanNet2 with attach_fbank(...) done (weights are copied into every slot)."""
+    def __init__(self, model, device, depth: int = 2, recurrent_tile: int = 0):
+        """model: a built uvad_amd.PyanNet2 with attach_fbank(...) done (weights are copied into every slot).
+        recurrent_tile: 0 = the library's per-call choice (fastest single call), 16 = the throughput form of the recurrence
+        (16 sequences per workgroup: ~3.5x fewer CU-cycles per sequence than the latency form, so more of the chip is free
+        for the other slots' kernels; a single call gets slower), 4 = the latency form."""
         if getattr(model, "_fbank_cfg", None) is None:
             raise RuntimeError("attach_fbank(FbankConfig(...)) first: the pipeline runs the fused PCM -> logits path")
         self.device = torch.device(device)
@@ -45,6 +48,8 @@ class ForwardPipeline:
         for _ in range(self.depth):
             r = VadRuntime(device=self.device, fbank=model._fbank_cfg, model=cfg)
             r.load_state_dict(model.state_dict())
+            if recurrent_tile:
+                r.set_recurrent_tile(recurrent_tile)
             self.runtimes.append(r)
         self.streams: Optional[List[torch.cuda.Stream]] = None
         self.streams_tried = 0
