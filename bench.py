@@ -9,9 +9,9 @@ reference) on the named frame shape.
 Workload (config.workload = BASELINE configs[1]): per GPU, B=256 utterances x 10 s of synthetic
 16 kHz audio, 25 ms / 10 ms frames, 64-bin log-mel (Hamming) + PyanNet2 classifier; a "step" is
 one pass of the whole hot path (uvad_forward: PCM resident in HBM -> per-frame logits in HBM) over
-that batch.  The K steps are submitted round-robin to three contexts / HIP streams (three steps in flight; every step
-does all of its work, see main()); --in-flight 1 submits them strictly one after the other (reported as the extra
-object "sequential").  N GPUs = N independent shards of 256 utterances (weak scaling, no data-path
+that batch.  The K steps are submitted round-robin to eight contexts / HIP streams (eight steps in flight, the recurrence in
+its throughput form; every step does all of its work, see main()); --in-flight 1 --rec-tile 0 submits them strictly one after
+the other with the library's latency-optimal choices (reported as the extra object "sequential").  N GPUs = N independent shards of 256 utterances (weak scaling, no data-path
 collective; utterance ids are disjoint across ranks).  value = frames all ranks processed / max
 over ranks of the time for exactly K steps bracketed by barrier + synchronize.
 
@@ -28,6 +28,10 @@ import json
 import os
 import sys
 import time
+
+# HIP maps streams onto a small pool of hardware queues (4 by default) and streams that share a queue serialise: the steps kept
+# in flight need one queue each.  Must be set before the HIP runtime starts (i.e. before torch is imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch
 
@@ -54,12 +58,12 @@ def classifier_flops_per_frame(F, H=128, L=4, D=2, lin=128, lin_layers=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU (default = BASELINE cfg 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=3, help="steps in flight (1 = strictly sequential submission, 3 = default)")
-    ap.add_argument("--rec-tile", type=int, default=0, choices=[0, 4, 16],
+    ap.add_argument("--in-flight", type=int, default=8, help="steps in flight (1 = strictly sequential submission, 8 = default)")
+    ap.add_argument("--rec-tile", type=int, default=16, choices=[0, 4, 16],
                     help="recurrent form of the in-flight contexts: 0 = the library's per-call choice, 4 = latency form, 16 = throughput form")
     ap.add_argument("--no-sequential", action="store_true", help="skip the extra strictly sequential measurement")
     ap.add_argument("--no-sincnet", action="store_true", help="skip the extra PyanNet (SincNet front end) measurement")
@@ -88,8 +92,9 @@ def main():
     model = model.to(dev).eval()
     # Several steps in flight (uvad_amd.ForwardPipeline): the K steps are submitted round-robin to n_fly contexts (own weights
     # copy, workspace and HIP stream each).  Every step is one complete uvad_forward over the batch; only the submission
-    # order of INDEPENDENT steps changes: while one step sits in its latency-bound recurrence (128 of the 256 CUs at
-    # B=256) the other step's feature kernel and projections run on the idle CUs.  --in-flight 1 = strictly sequential.
+    # order of INDEPENDENT steps changes.  The recurrence is a serial chain of 4 x T steps that cannot use the whole chip for
+    # one batch: in its throughput form (16 sequences per workgroup, --rec-tile 16) a batch of 256 occupies 32 CUs for ~2 ms
+    # per layer, and the other steps' feature kernels, projections and recurrences run on the rest.  --in-flight 1 = sequential.
     n_fly = max(1, min(args.in_flight, 8))
     pipe = uvad_amd.ForwardPipeline(model, dev, depth=n_fly, recurrent_tile=args.rec_tile)
     rts = pipe.runtimes
@@ -102,7 +107,10 @@ def main():
     def submit(k):
         return pipe.submit(pcm)
 
-    log(f"rank {rank}/{world}: inputs ready (B={B}, T={T}); warmup")
+    log(f"rank {rank}/{world}: inputs ready (B={B}, T={T}); one pass per context (allocations, kernel attributes), then warmup")
+    for r in rts:
+        r.forward(pcm, want_probs=False)
+    torch.cuda.synchronize(dev)
     for k in range(args.warmup):
         submit(k)
     torch.cuda.synchronize(dev)
@@ -148,14 +156,20 @@ def main():
         "head": {"ms": ms["head"], "bound": "mfma", "achieved_TFLOPs": frames_step * head_f / (ms["head"] * 1e-3) / 1e12},
     }
     stage["fbank"]["frac"] = stage["fbank"]["achieved_GBs"] / PEAK_HBM_GBS if stage["fbank"]["achieved_GBs"] else None
-    # The recurrence runs exact-f32 MFMAs: its fraction is against the f32-MFMA peak.  The projections and the feed-forward
-    # layers run gemm_f16p_kernel: FOUR f16 MFMA products per f32-equivalent product on the 2.5 PFLOP/s f16 pipe, so the
-    # honest pipe fraction is 4 x the f32-equivalent rate over the f16 peak; the f32-equivalent rate is kept as information only
-    # (it is NOT a fraction of the f32 peak: no f32 MFMA is issued).
-    stage["recurrent"]["frac"] = stage["recurrent"]["achieved_TFLOPs"] / PEAK_F32_MFMA_TFLOPS
-    stage["recurrent"]["peak"] = "f32 MFMA 157.3 TFLOP/s"
-    for k in ("proj", "head"):
-        stage[k]["kernel"] = "gemm_f16p_kernel" + (" + classifier_kernel" if k == "head" else "")
+    # The projections and the feed-forward layers (gemm_f16p_kernel) and the 16-sequence recurrence (lstm_rec16h_kernel) run
+    # FOUR f16 MFMA products per f32-equivalent product on the 2.5 PFLOP/s f16 pipe, so the honest pipe fraction is 4 x the
+    # f32-equivalent rate over the f16 peak; the f32-equivalent rate is kept as information only (it is NOT a fraction of the
+    # f32 peak: no f32 MFMA is issued).  The 4-sequence recurrence (lstm_rec_kernel) runs exact-f32 MFMAs: f32-MFMA peak.
+    rec_tile = rts[0].recurrent_tile()
+    rec_kernel = "lstm_rec16h_kernel<true>" if rec_tile == 16 else "lstm_rec_kernel<128, 8, true>"
+    f16_stages = ("proj", "head") + (("recurrent",) if rec_tile == 16 else ())
+    if rec_tile != 16:
+        stage["recurrent"]["frac"] = stage["recurrent"]["achieved_TFLOPs"] / PEAK_F32_MFMA_TFLOPS
+        stage["recurrent"]["peak"] = "f32 MFMA 157.3 TFLOP/s"
+    stage["recurrent"]["kernel"] = rec_kernel
+    for k in f16_stages:
+        if k != "recurrent":
+            stage[k]["kernel"] = "gemm_f16p_kernel" + (" + classifier_kernel" if k == "head" else "")
         stage[k]["f32_equivalent_TFLOPs"] = stage[k].pop("achieved_TFLOPs")
         stage[k]["f16_pipe_TFLOPs"] = 4.0 * stage[k]["f32_equivalent_TFLOPs"]
         stage[k]["frac"] = stage[k]["f16_pipe_TFLOPs"] / PEAK_F16_MFMA_TFLOPS
@@ -163,9 +177,12 @@ def main():
     # dominant kernel: the recurrent kernel (one launch per layer) or the projection GEMM (one per layer)
     L = 4
     if ms["recurrent"] >= ms["proj"]:
-        kern, flops_launch, dur_ms, peak = "lstm_rec_kernel<128, 8>", frames_step * rec_f / L, ms["recurrent"] / L, PEAK_F32_MFMA_TFLOPS
+        if rec_tile == 16:
+            kern, flops_launch, dur_ms, peak = rec_kernel, 4.0 * frames_step * rec_f / L, ms["recurrent"] / L, PEAK_F16_MFMA_TFLOPS
+        else:
+            kern, flops_launch, dur_ms, peak = rec_kernel, frames_step * rec_f / L, ms["recurrent"] / L, PEAK_F32_MFMA_TFLOPS
     else:
-        kern, flops_launch, dur_ms, peak = "gemm_f16p_kernel", 4.0 * frames_step * proj_f / L, ms["proj"] / L, PEAK_F16_MFMA_TFLOPS
+        kern, flops_launch, dur_ms, peak = "gemm_f16p_kernel<true>", 4.0 * frames_step * proj_f / L, ms["proj"] / L, PEAK_F16_MFMA_TFLOPS
     achieved = flops_launch / (dur_ms * 1e-3) / 1e12
     # HBM bytes per launch of that kernel from the rocprofv3 PMC passes of this same workload (FETCH_SIZE doubled
     # per MI355X_MICROARCH.md + WRITE_SIZE); bench.py cannot collect PMC counters itself, so the committed
@@ -175,7 +192,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath) and B == B_PER_GPU:
             kk = json.load(open(tpath))["kernels"]
-            key = next((k for k in kk if k.startswith("lstm_rec_kernel" if kern.startswith("lstm") else "gemm_f16p_kernel<false> grid=8192000")), None)
+            key = next((k for k in kk if k.startswith(kern.split("<")[0] if kern.startswith("lstm") else "gemm_f16p_kernel<true>")), None)
             if key in kk:
                 traffic, traffic_src = kk[key]["hbm_MB_per_launch"] * 1e6, "profiles/" + name
                 break
@@ -183,8 +200,9 @@ def main():
                 "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch",
                 "traffic_source": traffic_src, "avg_launch_ms": dur_ms, "flops_per_launch": flops_launch}
     if n_fly > 1:
-        roofline["note"] = ("launch duration measured while the other in-flight step's kernels share the GPU (this kernel owns 128 of the "
-                            "256 CUs at B=256); see sequential.roofline for the same launch with the GPU to itself")
+        roofline["note"] = ("launch duration measured while the other in-flight steps' kernels share the GPU (a recurrent launch owns "
+                            f"{B // rec_tile if rec_tile else '?'} of the 256 CUs, one workgroup of {rec_tile} sequences each; the recurrence is a serial chain, see "
+                            "DESIGN.md 3.2); see sequential.roofline for the latency-form launch with the GPU to itself")
 
     out = {
         "metric": "audio frames/sec (log-mel + PyanNet2 VAD forward); per-frame logit max-abs-err vs CPU ref",
@@ -203,7 +221,7 @@ def main():
                           "in flight the stages of different steps overlap (and slow each other down), so they do not add up to ms_per_step")
 
     if n_fly > 1 and not args.no_sequential:
-        out["sequential"] = sequential_latency(rts[0], dev, pcm, min(args.steps, 10), world)
+        out["sequential"] = sequential_latency(rts[0], dev, pcm, min(args.steps, 10), world, args.rec_tile)
     if args.scatter:
         out["scatter"] = scatter_leg(rt, dev, B, S, rank, world, min(args.steps, 10))
     if rank == 0 and world == 1 and not args.no_sincnet:
@@ -215,10 +233,11 @@ def main():
     udist.barrier()
 
 
-def sequential_latency(rt, dev, pcm, steps, world):
+def sequential_latency(rt, dev, pcm, steps, world, forced=0):
     """Extra, NOT the headline value: the same step submitted strictly one after the other on one stream (what a single
     caller without a second context sees): latency of one step and the throughput that goes with it."""
     from uvad_amd import dist as udist
+    rt.set_recurrent_tile(0)              # the library's own per-call choice (the 4-sequence latency form at this batch)
     rt.forward(pcm, want_probs=False)
     torch.cuda.synchronize(dev)
     udist.barrier()
@@ -236,11 +255,13 @@ def sequential_latency(rt, dev, pcm, steps, world):
         rt.forward(pcm, want_probs=False)
         rec += rt.timing_ms()["recurrent"]
     rt.set_timing(False)
+    used = rt.recurrent_tile()
+    rt.set_recurrent_tile(forced)
     _, rec_f, _ = classifier_flops_per_frame(N_MELS)
     launch_ms = rec / 3 / 4
     tf = pcm.shape[0] * rt.num_frames(pcm.shape[1]) * rec_f / 4 / (launch_ms * 1e-3) / 1e12
-    return {"value": frames / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps_in_flight": 1,
-            "roofline": {"kernel": "lstm_rec_kernel<128, 8>", "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+    return {"value": frames / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps_in_flight": 1, "recurrent_tile": used,
+            "roofline": {"kernel": "lstm_rec_kernel<128, 8, true>", "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": launch_ms},
             "note": "same step, one at a time on one stream; not the headline value"}
 

@@ -136,7 +136,8 @@ def test_cfg4_large_batch_throughput_recurrence_and_shard_invariance():
     pcm = (base.unsqueeze(0) * gain).reshape(B, S).contiguous()        # 4096 distinct utterances (64 signals x 64 gains)
     full, _ = rt.forward(pcm, want_probs=False)
     assert rt.recurrent_tile() == 16 == rt.recurrent_tile_for(B), "B = 4096 bidirectional must select the 16-sequence recurrent kernel"
-    assert rt.recurrent_tile_for(256) == 4 and rt.recurrent_tile_for(1024) == 4
+    assert rt.recurrent_tile_for(256) == 4 and rt.recurrent_tile_for(512) == 4    # one round of 4-sequence workgroups: latency form
+    assert rt.recurrent_tile_for(1024) == 16                                       # two rounds: the 16-sequence form is faster
     assert full.shape == (B, 1000) and torch.isfinite(full).all()
     # subset vs the CPU paths on identical features
     sub = [0, 1, 777, 2048, 4095]

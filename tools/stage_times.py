@@ -34,3 +34,9 @@ for _ in range(args.reps):
     for k, v in rt.timing_ms().items():
         acc[k] = acc.get(k, 0.0) + v / args.reps
 print(json.dumps({"lib": args.lib or "default", "mode": args.mode, "batch": args.batch, "tile": rt.recurrent_tile(), "ms": {k: round(v, 4) for k, v in acc.items()}}))
+if hasattr(rt.lib, "uvad_debug_stamps"):   # diagnostic builds with -DUVAD_R16_STAMP=<wave>: cycles per phase of the last launch, per step
+    import ctypes
+    buf = (ctypes.c_ulonglong * 8)()
+    rt.lib.uvad_debug_stamps(buf)
+    T = rt.num_frames(160000)
+    print(json.dumps({"r16_cycles_per_step": {n: round(buf[i] / T, 1) for i, n in enumerate(["h_frag_read", "mfma_and_cells", "h_write_and_store", "barrier"])}}))

@@ -48,16 +48,27 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-constexpr int BM = PLANE_TILE, BN = 64;
+constexpr int BM = PLANE_TILE, BN = 128, GT = 64;   // GT: column width of a tile of the blocked gate matrix (g_index)
 
-// LDS image of one 16-deep k-block (f16 elements): 128 rows of A hi, 128 of A lo, 64 rows each of W P0 / P1 / P2; a row is
-// 16 elements = two 16-byte chunks, chunk c of row r sits at slot c ^ ((r >> 3) & 1) (rows r and r + 8 share a bank line)
-constexpr int KB_AHI = 0, KB_ALO = BM * 16, KB_W0 = 2 * BM * 16, KB_W1 = KB_W0 + BN * 16, KB_W2 = KB_W1 + BN * 16, KB_ELEMS = KB_W2 + BN * 16;
+// LDS image of one 16-deep k-block (f16 elements): 128 rows each of A hi, A lo, W P0, W P1, W P2; a row is 16 elements = two
+// 16-byte chunks, chunk c of row r sits at slot c ^ ((r >> 3) & 1) (rows r and r + 8 share a bank line)
+constexpr int SLAB = 128 * 16;
+constexpr int KB_AHI = 0, KB_ALO = SLAB, KB_W0 = 2 * SLAB, KB_W1 = 3 * SLAB, KB_W2 = 4 * SLAB, KB_ELEMS = 5 * SLAB;
+static_assert(BM == 128 && BN == 128, "the DMA plan moves five 128-row slabs per k-block, one 32-row piece per wave each");
+
+#ifndef UVAD_F16P_NST
+#define UVAD_F16P_NST 2
+#endif
+#ifndef UVAD_F16P_OCC
+#define UVAD_F16P_OCC 3
+#endif
 
 template <bool OUT_PLANES>
-__global__ __launch_bounds__(256, 4) void gemm_f16p_kernel(GemmArgs a, int mt, int nt) {
-    constexpr int STAGE = KB_ELEMS, NST = 2;   // two LDS stages of one 16-deep k-block each
-    constexpr int LDS_ELEMS = NST * STAGE > BM * BN * 2 ? NST * STAGE : BM * BN * 2;   // the f32 output tile of the blocked epilogue aliases the stages
+__global__ __launch_bounds__(256, UVAD_F16P_OCC) void gemm_f16p_kernel(GemmArgs a, int mt, int nt) {
+    constexpr int STAGE = KB_ELEMS, NST = UVAD_F16P_NST;   // LDS stages of one 16-deep k-block each (20 KiB)
+    constexpr bool EPI_HALVES = NST * STAGE < BM * BN * 2;   // the f32 output tile of the blocked epilogue aliases the stages: whole, or one 128 x 64 half at a time
+    constexpr int EPI_ELEMS = EPI_HALVES ? BM * GT * 2 : BM * BN * 2;
+    constexpr int LDS_ELEMS = NST * STAGE > EPI_ELEMS ? NST * STAGE : EPI_ELEMS;
     __shared__ __attribute__((aligned(16))) unsigned short lds[LDS_ELEMS];
 
     if (a.gate && (*a.gate != 0) != (a.gate_run_if_set != 0)) return;   // device-side kernel selection (see GemmArgs)
@@ -70,126 +81,166 @@ __global__ __launch_bounds__(256, 4) void gemm_f16p_kernel(GemmArgs a, int mt, i
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- DMA plan.  Per k-block FOUR wave-instructions per wave:
-    //      a quarter of the A hi slab, a quarter of the A lo slab, a quarter of the W P0 slab (waves 0-1) or W P1 slab (waves 2-3),
-    //      and -- lanes 0-31 only -- a quarter of the W P2 slab.  A lane always fetches the chunk that belongs at its LDS slot
-    //      (slot s of row r holds chunk s ^ ((r >> 3) & 1)): bases are wave-uniform, lane offsets are constants.
+    // ---- DMA plan.  Per k-block FIVE wave-instructions per wave: rows [32 wave, 32 wave + 32) of each of the five slabs.  A lane
+    //      always fetches the chunk that belongs at its LDS slot (slot s of row r holds chunk s ^ ((r >> 3) & 1)): bases are
+    //      wave-uniform, the lane offset is one constant.
     const int nkb = a.K / 16;                                   // k-blocks of the whole contraction (K is a multiple of 32)
-    const unsigned short *a_hi = a.Ah + (size_t)m_tile * nkb * (BM * 16);
-    const unsigned short *a_lo = a.Al + (size_t)m_tile * nkb * (BM * 16);
-    const size_t wplane = (size_t)((a.N + BN - 1) / BN) * nkb * (BN * 16);   // elements per W plane (N padded to whole 64-row tiles)
-    const unsigned short *w_a = a.Wsplit16 + (wave < 2 ? 0 : wplane) + (size_t)n_tile * nkb * (BN * 16);   // P0 or P1
-    const unsigned short *w_2 = a.Wsplit16 + 2 * wplane + (size_t)n_tile * nkb * (BN * 16);
-    const int ra = tid >> 1, rw = (tid & 127) >> 1, q2 = wave * 32 + (lane & 31), r2 = q2 >> 1;
-    const unsigned off_a = (unsigned)((ra * 2 + ((tid & 1) ^ ((ra >> 3) & 1))) * 8);
-    const unsigned off_w = (unsigned)((rw * 2 + ((tid & 1) ^ ((rw >> 3) & 1))) * 8);
-    const unsigned off_2 = (unsigned)((r2 * 2 + ((q2 & 1) ^ ((r2 >> 3) & 1))) * 8);
+    const size_t wplane = (size_t)((a.N + BN - 1) / BN) * nkb * SLAB;   // elements per W plane (N padded to whole 128-row tiles)
+    const int ra = tid >> 1;
+    const unsigned off = (unsigned)((ra * 2 + ((tid & 1) ^ ((ra >> 3) & 1))) * 8);
+    const unsigned short *a_hi = a.Ah + (size_t)m_tile * nkb * SLAB + off;
+    const unsigned short *a_lo = a.Al + (size_t)m_tile * nkb * SLAB + off;
+    const unsigned short *w_0 = a.Wsplit16 + (size_t)n_tile * nkb * SLAB + off;
+    const unsigned short *w_1 = w_0 + wplane, *w_2 = w_0 + 2 * wplane;
     auto issue = [&](int stage, int kb) {
-        unsigned short *img = lds + stage * STAGE;
-        const size_t ka = (size_t)kb * (BM * 16), kw = (size_t)kb * (BN * 16);
-        __builtin_amdgcn_global_load_lds((gptr_t)(a_hi + ka + off_a), (lptr_t)(img + KB_AHI + wave * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(a_lo + ka + off_a), (lptr_t)(img + KB_ALO + wave * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(w_a + kw + off_w), (lptr_t)(img + KB_W0 + wave * 512), 16, 0, 0);   // waves 2-3 land in KB_W1
-        if (lane < 32) __builtin_amdgcn_global_load_lds((gptr_t)(w_2 + kw + off_2), (lptr_t)(img + KB_W2 + wave * 256), 16, 0, 0);
+        unsigned short *img = lds + stage * STAGE + wave * 512;
+        const size_t k = (size_t)kb * SLAB;
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_hi + k), (lptr_t)(img + KB_AHI), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_lo + k), (lptr_t)(img + KB_ALO), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_0 + k), (lptr_t)(img + KB_W0), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_1 + k), (lptr_t)(img + KB_W1), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_2 + k), (lptr_t)(img + KB_W2), 16, 0, 0);
     };
 
-    f32x16 hi0, hi1, lo0, lo1;
+    // accumulators of the wave's 64 x 64 tile: [row block][column block], hi and lo sets
+    f32x16 hi[2][2], lo[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { hi0[r] = 0.f; hi1[r] = 0.f; lo0[r] = 0.f; lo1[r] = 0.f; }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
 
-    // fragment addresses (f16 elements inside a k-block image): lane = (row fr of the 32-row MFMA tile, k-half fh)
+    // fragment addresses (f16 elements inside a slab): lane = (row fr of the 32-row MFMA tile, k-half fh)
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 31, fh = lane >> 5;
-    const int arow0 = wr * 64 + fr, arow1 = arow0 + 32, wrow = wc * 32 + fr;
-    const int fa0 = arow0 * 16 + ((fh ^ ((arow0 >> 3) & 1)) * 8), fa1 = arow1 * 16 + ((fh ^ ((arow1 >> 3) & 1)) * 8);
-    const int fw = wrow * 16 + ((fh ^ ((wrow >> 3) & 1)) * 8);
+    int fa[2], fw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ar = wr * 64 + i * 32 + fr, wrw = wc * 64 + i * 32 + fr;
+        fa[i] = ar * 16 + ((fh ^ ((ar >> 3) & 1)) * 8);
+        fw[i] = wrw * 16 + ((fh ^ ((wrw >> 3) & 1)) * 8);
+    }
 
-    // ---- k loop: plain double buffer, one barrier per k-block; the DMA of k-block kt + 1 is in flight during the MFMAs of kt.
-    //      (A 3- and a 4-stage ring with counted vmcnt waits and raw barriers measured the same 2.27 ms for the four projections:
-    //      with five workgroups per CU the k loop runs the f16 matrix pipe at ~65 %, it is not waiting for the DMA.)
-    issue(0, 0);
+    // ---- k loop: one barrier per k-block; the DMA of the next k-block(s) is in flight during the MFMAs of this one.
+    //      Per wave and k-block: 10 ds_read_b128 and 16 MFMAs (4 products x 2 x 2 tiles); per workgroup 20 KiB through the
+    //      vector memory path for 64 MFMAs (the 128 x 64 tile of the first version moved 14 KiB per 32 MFMAs and was bound by
+    //      exactly that: TA busy 77-86 %, matrix pipe 65 % inside the k loop).
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+        if (p < nkb) issue(p, p);
     for (int kt = 0; kt < nkb; ++kt) {
-        __syncthreads();   // (hipcc waits vmcnt(0) here) k-block kt has landed for every wave; everyone is done reading k-block kt-1
+        if constexpr (NST == 2) {
+            __syncthreads();   // (hipcc waits vmcnt(0) here) k-block kt has landed for every wave; everyone is done reading k-block kt-1
+        } else {
+            // k-blocks kt .. kt+NST-2 are in flight (5 loads each, fewer at the tail): wait for the oldest only
+            if (kt + NST - 2 < nkb) __builtin_amdgcn_s_waitcnt(0x0f70 | (5 * (NST - 2) & 0xf) | (((5 * (NST - 2)) >> 4) << 14));
+            else __builtin_amdgcn_s_waitcnt(0x0f70);
+            __builtin_amdgcn_s_barrier();
+        }
 #ifndef UVAD_F16P_ABL_NODMA   // diagnostic builds (tools/stage_times.py --lib): outputs of ablated builds are meaningless
-        if (kt + 1 < nkb) issue((kt + 1) % NST, kt + 1);
+        if (kt + NST - 1 < nkb) issue((kt + NST - 1) % NST, kt + NST - 1);
 #endif
         const unsigned short *st = lds + (kt % NST) * STAGE;
-        const f16x8 a0h = *reinterpret_cast<const f16x8 *>(st + KB_AHI + fa0);
-        const f16x8 a0l = *reinterpret_cast<const f16x8 *>(st + KB_ALO + fa0);
-        const f16x8 a1h = *reinterpret_cast<const f16x8 *>(st + KB_AHI + fa1);
-        const f16x8 a1l = *reinterpret_cast<const f16x8 *>(st + KB_ALO + fa1);
-        const f16x8 w0 = *reinterpret_cast<const f16x8 *>(st + KB_W0 + fw);
-        const f16x8 w1 = *reinterpret_cast<const f16x8 *>(st + KB_W1 + fw);
-        const f16x8 w2 = *reinterpret_cast<const f16x8 *>(st + KB_W2 + fw);
+        f16x8 ah[2], al[2], w0[2], w1[2], w2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8 *>(st + KB_AHI + fa[i]);
+            w0[i] = *reinterpret_cast<const f16x8 *>(st + KB_W0 + fw[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            w1[i] = *reinterpret_cast<const f16x8 *>(st + KB_W1 + fw[i]);
+            al[i] = *reinterpret_cast<const f16x8 *>(st + KB_ALO + fa[i]);
+            w2[i] = *reinterpret_cast<const f16x8 *>(st + KB_W2 + fw[i]);
+        }
 #ifdef UVAD_F16P_ABL_NOMFMA
-        asm volatile("" ::"v"(a0h), "v"(a0l), "v"(a1h), "v"(a1l), "v"(w0), "v"(w1), "v"(w2));
+        asm volatile("" ::"v"(ah[0]), "v"(al[0]), "v"(ah[1]), "v"(al[1]), "v"(w0[0]), "v"(w1[0]), "v"(w2[0]), "v"(w0[1]), "v"(w1[1]), "v"(w2[1]));
         continue;
 #endif
-        lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w1, lo0, 0, 0, 0);
-        lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w1, lo1, 0, 0, 0);
-        lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, w0, lo0, 0, 0, 0);
-        lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, w0, lo1, 0, 0, 0);
-        lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w2, lo0, 0, 0, 0);
-        lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w2, lo1, 0, 0, 0);
-        hi0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w0, hi0, 0, 0, 0);
-        hi1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w0, hi1, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], w0[j], hi[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], w1[j], lo[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], w0[j], lo[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], w2[j], lo[i][j], 0, 0, 0);
     }
 
     // ---- epilogue: (hi + lo * 2^-11) * 2^-S + bias, activation.  C layout of the 32x32 MFMA: register r of lane (fr, fh) =
     //      row 8*(r>>2) + 4*fh + (r&3), column fr.
-    const int col = C0 + wc * 32 + fr;
-    const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;
     if (!OUT_PLANES && a.c_blocked) {
-        // Tile-blocked gate matrix: this workgroup's 128 x 64 tile is ONE contiguous 32 KiB run of G (whole tiles exist for
-        // the padding rows too), so the tile goes through LDS and leaves as unmasked 16-byte stores, 1 KiB per wave-instruction
-        // (dword stores straight from the accumulators measured 2.9 TB/s and did not overlap with the K loops).
+        // Tile-blocked gate matrix: this workgroup's 128 x 128 tile is two adjacent 128 x 64 tiles of G = ONE contiguous 64 KiB
+        // run (whole tiles exist for the padding rows too), so the tile goes through LDS and leaves as unmasked 16-byte
+        // stores, 1 KiB per wave-instruction (dword stores straight from the accumulators measured 2.9 TB/s and did not
+        // overlap with the K loops).
         float *Ct = reinterpret_cast<float *>(lds);
-        __syncthreads();   // every wave is done reading the last stage
+        float *dst = a.C + ((size_t)m_tile * (a.N / GT) + (size_t)n_tile * (BN / GT)) * (BM * GT);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const f32x16 &HI = mi ? hi1 : hi0;
-            const f32x16 &LO = mi ? lo1 : lo0;
+        for (int half = 0; half < (EPI_HALVES ? 2 : 1); ++half) {
+            __syncthreads();   // every wave is done reading the last stage / storing the previous half
+            if (!EPI_HALVES || wc == half) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lr = wr * 64 + mi * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
-                Ct[lr * BN + wc * 32 + fr] = __builtin_fmaf(__builtin_fmaf(LO[r], 0.00048828125f, HI[r]), a.wscale, bias);
+                for (int j = 0; j < 2; ++j) {
+                    const int lc = wc * 64 + j * 32 + fr;                    // column inside the 128-wide tile
+                    const float bias = a.bias ? a.bias[C0 + lc] : 0.f;
+                    float *Cj = Ct + (EPI_HALVES ? 0 : (lc / GT) * (BM * GT)) + (lc % GT);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int lr = wr * 64 + i * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+                            Cj[lr * GT] = __builtin_fmaf(__builtin_fmaf(lo[i][j][r], 0.00048828125f, hi[i][j][r]), a.wscale, bias);
+                        }
+                }
             }
-        }
-        __syncthreads();
-        float *dst = a.C + ((size_t)m_tile * (a.N / BN) + n_tile) * (BM * BN);
+            __syncthreads();
+            constexpr int N4 = (EPI_HALVES ? BM * GT : BM * BN) / 4;
 #pragma unroll
-        for (int j = 0; j < BM * BN / 4 / 256; ++j) {
-            const int q = tid + 256 * j;
+            for (int j = 0; j < N4 / 256; ++j) {
+                const int q = tid + 256 * j;
 #ifdef UVAD_F16P_ABL_NOSTORE
-            if (Ct[q * 4] == 12345.678f)
+                if (Ct[q * 4] == 12345.678f)
 #endif
-            *reinterpret_cast<float4 *>(dst + (size_t)q * 4) = *reinterpret_cast<const float4 *>(Ct + q * 4);
+                *reinterpret_cast<float4 *>(dst + (size_t)half * (BM * GT) + (size_t)q * 4) = *reinterpret_cast<const float4 *>(Ct + q * 4);
+            }
         }
         return;
     }
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const f32x16 &HI = mi ? hi1 : hi0;
-        const f32x16 &LO = mi ? lo1 : lo0;
+    for (int j = 0; j < 2; ++j) {
+        const int col = C0 + wc * 64 + j * 32 + fr;
+        const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = R0 + wr * 64 + mi * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
-            float v = __builtin_fmaf(__builtin_fmaf(LO[r], 0.00048828125f, HI[r]), a.wscale, bias);
-            if (a.act == 1) v = v >= 0.f ? v : a.leaky_slope * v;
-            if constexpr (OUT_PLANES) {
-                // consumer = another f16p GEMM whose K is ldc (N rounded up to 32): its padding columns must read as zero
-                if (row < a.M && col < a.ldc) {
-                    if (col >= a.N) v = 0.f;
-                    const _Float16 h = (_Float16)v;
-                    const _Float16 l = (_Float16)((v - (float)h) * 2048.0f);
-                    const size_t o = plane_index(row, col, a.ldc);
-                    a.Ch[o] = __builtin_bit_cast(unsigned short, h);
-                    a.Cl[o] = __builtin_bit_cast(unsigned short, l);
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = R0 + wr * 64 + i * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+                float v = __builtin_fmaf(__builtin_fmaf(lo[i][j][r], 0.00048828125f, hi[i][j][r]), a.wscale, bias);
+                if (a.act == 1) v = v >= 0.f ? v : a.leaky_slope * v;
+                if constexpr (OUT_PLANES) {
+                    // consumer = another f16p GEMM whose K is ldc (N rounded up to 32): its padding columns must read as zero
+                    if (row < a.M && col < a.ldc) {
+                        if (col >= a.N) v = 0.f;
+                        const _Float16 h = (_Float16)v;
+                        const _Float16 l = (_Float16)((v - (float)h) * 2048.0f);
+                        const size_t o = plane_index(row, col, a.ldc);
+                        a.Ch[o] = __builtin_bit_cast(unsigned short, h);
+                        a.Cl[o] = __builtin_bit_cast(unsigned short, l);
+                    }
+                } else {
+                    if (row < a.M && col < a.N) a.C[(size_t)row * a.ldc + col] = v;
                 }
-            } else {
-                if (row < a.M && col < a.N) a.C[(size_t)row * a.ldc + col] = v;
             }
-        }
     }
 }
 
@@ -232,7 +283,7 @@ __global__ __launch_bounds__(256) void split_features_kernel(const float *x, int
 int gemm_f16p_padded_k(int K) { return (K + 31) / 32 * 32; }
 
 // host: f32 [N][ldw] (rows zero-padded to ldw, a multiple of 32) -> three f16 planes of w * 2^S that add up to it EXACTLY (see the
-// header), each in the K-blocked layout with 64-row tiles (N padded to whole tiles with zero rows): out holds
+// header), each in the K-blocked layout with 128-row tiles (N padded to whole tiles with zero rows): out holds
 // 3 * weight_plane_elems(N, ldw) elements; *wscale = 2^-S.  false: a weight is non-finite (the matrix cannot be represented).
 size_t weight_plane_elems(int N, int ldw) { return (size_t)((N + BN - 1) / BN) * BN * ldw; }
 
@@ -277,7 +328,7 @@ hipError_t launch_gemm_f16p(const GemmArgs &a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     if (!a.Ah || !a.Al || !a.Wsplit16 || a.K <= 0 || (a.K & 31) || a.ldw != a.K) return hipErrorInvalidValue;
     if (a.out_planes ? (!a.Ch || !a.Cl) : !a.C) return hipErrorInvalidValue;
-    if (a.c_blocked && (a.out_planes || a.act != 0 || a.N % BN != 0)) return hipErrorInvalidValue;   // the gate matrix: whole 64-column tiles, no activation
+    if (a.c_blocked && (a.out_planes || a.act != 0 || a.N % BN != 0)) return hipErrorInvalidValue;   // the gate matrix: whole 128-column tiles, no activation
     const int mt = (a.M + BM - 1) / BM, nt = ((a.out_planes ? a.ldc : a.N) + BN - 1) / BN;
     const int grid = ((mt + 7) / 8) * 8 * nt;
     if (a.out_planes)

@@ -78,6 +78,45 @@ __device__ __forceinline__ float lstm_cell(const f32x4 g, float &c) {
 #endif
 }
 
+// Two cell updates at once for the 16-sequence kernel, which is bound by vector-instruction issue (four cells per lane and
+// step): the arithmetic runs as packed f32 pairs (v_pk_mul/add/fma_f32: two cells per instruction) and two of the five
+// reciprocals per cell disappear by dividing once per PRODUCT,
+//     sigmoid(i) * tanh(g) = sign(g) (1 - eg) / ((1 + ei)(1 + eg)),   sigmoid(o) * tanh(c) = sign(c) (1 - ec) / ((1 + eo)(1 + ec))
+// with e* = exp2 of the clamped negated pre-activation as in sigmoid_f / tanh_f (the denominators stay below 2^127: ei <= 2^125,
+// eg <= 1).  Each quotient is v_rcp_f32 + one Newton step on the quotient, i.e. correctly rounded up to 2^-46 like tanh_f's.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ f32x2 exp2_2(f32x2 x) { return f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])}; }
+__device__ __forceinline__ f32x2 quot_2(f32x2 n, f32x2 d) {   // n / d, d in [1, 2^127)
+    const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32x2 q = n * r;
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(-d, q, n), r, q);
+}
+__device__ __forceinline__ void lstm_cell2(const f32x4 ga, const f32x4 gb, float &ca, float &cb, float &ha, float &hb) {
+#if defined(UVAD_ABL_NOGATE) || defined(UVAD_FAST_GATES)
+    ha = lstm_cell(ga, ca);
+    hb = lstm_cell(gb, cb);
+#else
+    const f32x2 one = {1.0f, 1.0f};
+    const f32x2 xi = {ga[0], gb[0]}, xf = {ga[1], gb[1]}, xo = {ga[3], gb[3]};
+    f32x2 ai = xi * -L2E, af = xf * -L2E, ao = xo * -L2E;
+    ai = f32x2{__builtin_fminf(ai[0], 125.0f), __builtin_fminf(ai[1], 125.0f)};
+    af = f32x2{__builtin_fminf(af[0], 125.0f), __builtin_fminf(af[1], 125.0f)};
+    ao = f32x2{__builtin_fminf(ao[0], 125.0f), __builtin_fminf(ao[1], 125.0f)};
+    const f32x2 ag = {(-2.0f * L2E) * __builtin_fabsf(ga[2]), (-2.0f * L2E) * __builtin_fabsf(gb[2])};
+    const f32x2 ei = exp2_2(ai), ef = exp2_2(af), eg = exp2_2(ag), eo = exp2_2(ao);
+    f32x2 itg = quot_2(one - eg, (one + ei) * (one + eg));                      // sigmoid(i) * |tanh(g)|
+    itg = f32x2{__builtin_copysignf(itg[0], ga[2]), __builtin_copysignf(itg[1], gb[2])};
+    const f32x2 fg = quot_2(one, one + ef);
+    const f32x2 c = __builtin_elementwise_fma(fg, f32x2{ca, cb}, itg);
+    ca = c[0];
+    cb = c[1];
+    const f32x2 ec = exp2_2(f32x2{(-2.0f * L2E) * __builtin_fabsf(c[0]), (-2.0f * L2E) * __builtin_fabsf(c[1])});
+    const f32x2 h = quot_2(one - ec, (one + eo) * (one + ec));                  // sigmoid(o) * |tanh(c)|
+    ha = __builtin_copysignf(h[0], c[0]);
+    hb = __builtin_copysignf(h[1], c[1]);
+#endif
+}
+
 // Gate prefetch: plain loads into a ring of PD register slots (the time loop is unrolled by PD so
 // every slot is a fixed register).  An inline-asm load with hand-counted vmcnt was tried and
 // measured no faster, and it is fragile (hipcc may reuse an asm load's destination before the data
@@ -302,9 +341,22 @@ constexpr int R16_HB_ELEMS = 2 * 2 * 16 * R16_HP;    // [buffer][plane][sequence
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
+#ifdef UVAD_R16_STAMP   // diagnostic build: cycle stamps of one wave of workgroup (0, 0) (read back with uvad_debug_stamps)
+__device__ unsigned long long g_r16_stamps[8];
+#define R16_STAMP(i)                                                     \
+    if (stamp_on) {                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+        const unsigned long long now = __builtin_readcyclecounter();     \
+        st_acc[i] += now - st_prev;                                      \
+        st_prev = now;                                                   \
+    }
+#else
+#define R16_STAMP(i)
+#endif
+
 template <bool PLANES>
 __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
-    constexpr int H = 128, RB = 4, KST = 4, PD16 = 1;   // the gates of a row block are re-requested for the next step as soon as this step has consumed them
+    constexpr int H = 128, RB = 4, KST = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned short sm16[];
     unsigned short *p2 = sm16, *hb = sm16 + R16_P2_ELEMS;
 
@@ -340,59 +392,74 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
     const size_t g_wave = (size_t)(dir * 8 + wave) * (128 * 64) + 4 * q, g_tile = (size_t)(a.ldg / 64) * (128 * 64);
     const size_t y_tile = (size_t)(a.ldy / 16) * (PLANE_TILE * 16);
     const size_t ycol = (size_t)dir * H + ubase;
-    auto g_ptr = [&](int t) {
-        const size_t R = row0 + (size_t)t * SEQ_TILE;
-        return a.G + (R >> 7) * g_tile + g_wave + (R & 127) * 64;
-    };
     const float wscale = a.whh16h_scale[dir];
+    // Row pointers are stepped, not recomputed (the kernel is bound by vector-instruction issue): a step moves 4 rows inside a
+    // 128-row tile of the blocked layouts (g_index / plane_index) or, on a wrap, to the neighbouring tile.
+    const int sgn = reverse ? -1 : 1, t_first = reverse ? a.T - 1 : 0;
+    const int g_in = 4 * 64 * sgn, g_wrap = ((int)g_tile - 124 * 64) * sgn;
+    const int y_in = 4 * 16 * sgn, y_wrap = ((int)y_tile - 124 * 16) * sgn;
+    auto advance = [&](auto *&ptr, int &rl, int d_in, int d_wrap) {
+        rl += 4 * sgn;
+        const bool wrap = (unsigned)rl >= 128u;
+        rl &= 127;
+        ptr += (ptrdiff_t)(wrap ? d_wrap : d_in);
+    };
+    int g_rl;
+    const float *g_p;
+    {
+        const size_t R = row0 + (size_t)t_first * SEQ_TILE;
+        g_rl = (int)(R & 127);
+        g_p = a.G + (R >> 7) * g_tile + g_wave + (size_t)g_rl * 64;
+    }
 
     float c[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) c[rb] = 0.0f;
-    f32x4 gq[PD16][RB];
+    f32x4 gq[RB];
 #pragma unroll
-    for (int p = 0; p < PD16; ++p) {
-        const int sp = p < a.T ? p : a.T - 1;
-        const int t = reverse ? a.T - 1 - sp : sp;
-        const float *gp = g_ptr(t);
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) gq[p][rb] = *reinterpret_cast<const f32x4 *>(gp + 16 * rb);
-    }
+    for (int rb = 0; rb < RB; ++rb) gq[rb] = *reinterpret_cast<const f32x4 *>(g_p + 16 * rb);
     __syncthreads();
 
     // Cooperative store of h_t as the two K-blocked f16 planes: the whole workgroup's output of a step is 8 KiB (2 planes x 16
     // sequences x 128 units), laid out in HBM as 64 runs of 128 bytes (4 sequence rows x 16 units); after the barrier it sits
     // complete in the LDS image the next step reads its B fragments from, and every thread moves ONE 16-byte piece of it
     // (per-lane 2-byte stores straight from the cell update cost 37 % of the kernel).
-    auto coop_store = [&](const unsigned short *himg, int t) {
+    // thread -> (plane, tile of 4 sequences, 16-unit block, row in tile, 16-byte half)
+    int c_rl = 0, c_src = 0;
+    unsigned short *c_p = nullptr;
+    bool clive = false;
+    if constexpr (PLANES) {
+        const int tid = threadIdx.x;
+        const int cp = tid >> 8, ctt = (tid >> 6) & 3, ckb = (tid >> 3) & 7, cjb = (tid >> 1) & 3, chh = tid & 1;
+        const int ct4 = tile16 * 4 + ctt;
+        clive = ct4 < a.tiles;
+        const size_t R = (size_t)(clive ? ct4 : a.tiles - 1) * a.T * SEQ_TILE + cjb + (size_t)t_first * SEQ_TILE;
+        c_rl = (int)(R & 127);
+        c_p = (cp ? a.Yl : a.Yh) + (R >> 7) * y_tile + (size_t)(dir * 8 + ckb) * (PLANE_TILE * 16) + chh * 8 + (size_t)c_rl * 16;
+        c_src = cp * (16 * R16_HP) + (ctt * 4 + cjb) * R16_HP + ckb * 16 + chh * 8;
+    }
+    auto coop_store = [&](const unsigned short *himg, bool step) {   // stores the frame c_p points at, then (step) moves on to the next
         if constexpr (PLANES) {
-            // thread -> (plane, tile of 4 sequences, 16-unit block, row in tile, 16-byte half); recomputed every step from an
-            // opaque copy of the thread id so that none of it occupies registers across the MFMA section
-            int tid = threadIdx.x;
-            asm volatile("" : "+v"(tid));
-            const int cp = tid >> 8, ctt = (tid >> 6) & 3, ckb = (tid >> 3) & 7, cjb = (tid >> 1) & 3, chh = tid & 1;
-            const int ct4 = tile16 * 4 + ctt;
-            const bool clive = ct4 < a.tiles;
-            const size_t R = (size_t)(clive ? ct4 : a.tiles - 1) * a.T * SEQ_TILE + cjb + (size_t)t * SEQ_TILE;
-            const uint4 v = *reinterpret_cast<const uint4 *>(himg + cp * (16 * R16_HP) + (ctt * 4 + cjb) * R16_HP + ckb * 16 + chh * 8);
-            unsigned short *plane = cp ? a.Yl : a.Yh;
-            if (clive) *reinterpret_cast<uint4 *>(plane + (R >> 7) * y_tile + (size_t)(dir * 8 + ckb) * (PLANE_TILE * 16) + chh * 8 + (R & 127) * 16) = v;
+            const uint4 v = *reinterpret_cast<const uint4 *>(himg + c_src);
+            if (clive) *reinterpret_cast<uint4 *>(c_p) = v;
+            if (step) advance(c_p, c_rl, y_in, y_wrap);
         }
     };
 
     const unsigned short *p2w = p2 + (size_t)(wave * 16) * 512 + lane * 8;   // fragment (rb, ks) at + (rb*4 + ks) * 512
     const int hfrag = j * R16_HP + 8 * q;                                   // + 32 ks inside a plane
-    for (int s0 = 0; s0 < a.T; s0 += PD16) {
-#pragma unroll
-      for (int u2 = 0; u2 < PD16; ++u2) {
-        const int s = s0 + u2;
-        if (s >= a.T) break;   // wave-uniform
+#ifdef UVAD_R16_STAMP
+    const bool stamp_on = wave == UVAD_R16_STAMP && blockIdx.x == 0 && blockIdx.y == 0;
+    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
+#endif
+    for (int s = 0; s < a.T; ++s) {
         const int t = reverse ? a.T - 1 - s : s;
 #pragma unroll
         for (int k = 0; k < 32; ++k) asm volatile("" : "+a"(w[k]));   // P0 / P1 stay in AGPRs (constraint only)
+        R16_STAMP(3)   // [3] = barrier wait (+ loop overhead)
 
-        const int spn = s + 1 < a.T ? s + 1 : a.T - 1;
-        const float *gnext = g_ptr(reverse ? a.T - 1 - spn : spn);
+        if (s + 1 < a.T) advance(g_p, g_rl, g_in, g_wrap);   // the gates of the next step (the last step re-reads its own)
+        const float *gnext = g_p;
         const unsigned short *hcur = hb + (s & 1) * (2 * 16 * R16_HP);
         unsigned short *hnxt = hb + ((s + 1) & 1) * (2 * 16 * R16_HP);
         f16x8 h1[KST], h2[KST];
@@ -401,12 +468,14 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
             h1[ks] = *reinterpret_cast<const f16x8 *>(hcur + hfrag + 32 * ks);
             h2[ks] = *reinterpret_cast<const f16x8 *>(hcur + 16 * R16_HP + hfrag + 32 * ks);
         }
+        R16_STAMP(0)   // [0] = h fragments read from LDS
         const size_t yrow = row0 + (size_t)t * SEQ_TILE;
         // Row blocks one after the other (16 MFMAs each); the P2 fragment of MFMA group f + 1 is requested from LDS before group f.
         // The kernel is bound by vector-instruction issue (~290 per wave and step: four cell updates per lane), not by the matrix
         // pipe (40 % busy), so scheduling is left to the compiler: staging the cell update of row block rb between the MFMA
         // groups of rb + 1 behind sched_barriers measured 10 % slower, a forced [4 MFMA, 1 LDS read] cadence 3 % slower.
         float hnew[RB];
+        f32x4 gpre[RB];
         f16x8 w2n = *reinterpret_cast<const f16x8 *>(p2w);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
@@ -428,14 +497,14 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
                 lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, h1[ks], lo, 0, 0, 0);
 #endif
             }
-            f32x4 g;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = __builtin_fmaf(__builtin_fmaf(lo[e], 0.00048828125f, hi[e]), wscale, gq[u2][rb][e]);
+            gpre[rb] = __builtin_elementwise_fma(__builtin_elementwise_fma(lo, f32x4{0.00048828125f, 0.00048828125f, 0.00048828125f, 0.00048828125f}, hi),
+                                                 f32x4{wscale, wscale, wscale, wscale}, gq[rb]);
 #ifndef UVAD_R16_NOGLOAD
-            gq[u2][rb] = *reinterpret_cast<const f32x4 *>(gnext + 16 * rb);   // next step's gates of this row block: a whole step to arrive
+            gq[rb] = *reinterpret_cast<const f32x4 *>(gnext + 16 * rb);   // next step's gates of this row block: a whole step to arrive
 #endif
-            hnew[rb] = lstm_cell(g, c[rb]);
+            if (rb & 1) lstm_cell2(gpre[rb - 1], gpre[rb], c[rb - 1], c[rb], hnew[rb - 1], hnew[rb]);   // two cells per packed instruction
         }
+        R16_STAMP(1)   // [1] = MFMAs + cell updates
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const int u = ubase + 4 * rb;
@@ -449,16 +518,20 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
         }
         // h of the PREVIOUS step (complete in LDS since the last barrier, not overwritten before the next one) goes out now,
         // when the fragment registers of this step are dead
-        if (s > 0) coop_store(hcur, reverse ? t + 1 : t - 1);
+        if (s > 0) coop_store(hcur, true);
+        R16_STAMP(2)   // [2] = h split + LDS writes + plane store
         __syncthreads();
-      }
     }
-    if (a.T > 0) coop_store(hb + (a.T & 1) * (2 * 16 * R16_HP), reverse ? 0 : a.T - 1);
+    if (a.T > 0) coop_store(hb + (a.T & 1) * (2 * 16 * R16_HP), false);
+#ifdef UVAD_R16_STAMP
+    if (stamp_on && lane == 0)
+        for (int i = 0; i < 4; ++i) g_r16_stamps[i] = st_acc[i];
+#endif
 }
 
 }  // namespace
 
-constexpr double REC16_ROUND_COST = 3.0;   // time of one round of the 16-sequence form / one round of the 4-sequence form
+constexpr double REC16_ROUND_COST = 1.6;   // time of one round of the 16-sequence form / one round of the 4-sequence form (1.94 vs 1.33 ms per layer at T = 1000; 2.2 ms with every CU busy)
 
 size_t whh_packed_elems(int H) { return (size_t)4 * H * H; }
 size_t whh16h_regs_elems() { return (size_t)8 * 128 * 64; }        // u32 per direction
@@ -581,3 +654,9 @@ hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
 }
 
 }  // namespace uvad
+
+#ifdef UVAD_R16_STAMP
+extern "C" int uvad_debug_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(uvad::g_r16_stamps), 8 * sizeof(unsigned long long));
+}
+#endif
