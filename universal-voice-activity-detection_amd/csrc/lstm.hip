@@ -487,21 +487,14 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
                 if (f + 1 < 16) w2n = *reinterpret_cast<const f16x8 *>(p2w + (f + 1) * 512);
                 const f16x8 w0 = __builtin_bit_cast(f16x8, w[f]);
                 const f16x8 w1 = __builtin_bit_cast(f16x8, w[16 + f]);
-#ifdef UVAD_R16_NOMFMA
-                asm volatile("" ::"v"(w0), "v"(w1), "v"(w2), "v"(h1[ks]), "v"(h2[ks]));
-                lo[0] += (float)w2[0];
-#else
                 lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, h1[ks], lo, 0, 0, 0);
                 hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, h1[ks], hi, 0, 0, 0);
                 lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, h2[ks], lo, 0, 0, 0);
                 lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, h1[ks], lo, 0, 0, 0);
-#endif
             }
             gpre[rb] = __builtin_elementwise_fma(__builtin_elementwise_fma(lo, f32x4{0.00048828125f, 0.00048828125f, 0.00048828125f, 0.00048828125f}, hi),
                                                  f32x4{wscale, wscale, wscale, wscale}, gq[rb]);
-#ifndef UVAD_R16_NOGLOAD
             gq[rb] = *reinterpret_cast<const f32x4 *>(gnext + 16 * rb);   // next step's gates of this row block: a whole step to arrive
-#endif
             if (rb & 1) lstm_cell2(gpre[rb - 1], gpre[rb], c[rb - 1], c[rb], hnew[rb - 1], hnew[rb]);   // two cells per packed instruction
         }
         R16_STAMP(1)   // [1] = MFMAs + cell updates
@@ -528,6 +521,7 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
         for (int i = 0; i < 4; ++i) g_r16_stamps[i] = st_acc[i];
 #endif
 }
+
 
 }  // namespace
 
@@ -622,15 +616,15 @@ hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
     if (a.tile_mode == 16 && !can16) return hipErrorInvalidValue;
     const bool planes = a.Y == nullptr;
     if (planes && (!a.Yh || !a.Yl)) return hipErrorInvalidValue;
-    const bool pick16 = lstm_auto_tile(a.tiles, a.dirs, a.H, a.n_cu) == 16;
-    if (can16 && (a.tile_mode == 16 || (a.tile_mode == 0 && pick16))) {
+    const int pick = a.tile_mode ? a.tile_mode : lstm_auto_tile(a.tiles, a.dirs, a.H, a.n_cu);
+    if (can16 && pick == 16) {
         if (tile_used) *tile_used = 16;
         const dim3 grid16((a.tiles + 3) / 4, a.dirs);
         const size_t lds = (size_t)(R16_P2_ELEMS + R16_HB_ELEMS) * sizeof(unsigned short);   // 145 KiB: one workgroup per CU
         static bool attr_set[2] = {false, false};
         if (!attr_set[planes]) {
-            const hipError_t e = planes ? hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_rec16h_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                                        : hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_rec16h_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            const void *fn = planes ? reinterpret_cast<const void *>(lstm_rec16h_kernel<true>) : reinterpret_cast<const void *>(lstm_rec16h_kernel<false>);
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             attr_set[planes] = true;
         }
