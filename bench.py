@@ -58,7 +58,7 @@ def classifier_flops_per_frame(F, H=128, L=4, D=2, lin=128, lin_layers=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU (default = BASELINE cfg 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -182,7 +182,7 @@ def main():
         else:
             kern, flops_launch, dur_ms, peak = rec_kernel, frames_step * rec_f / L, ms["recurrent"] / L, PEAK_F32_MFMA_TFLOPS
     else:
-        kern, flops_launch, dur_ms, peak = "gemm_f16p_kernel<true>", 4.0 * frames_step * proj_f / L, ms["proj"] / L, PEAK_F16_MFMA_TFLOPS
+        kern, flops_launch, dur_ms, peak = "gemm_f16p_kernel<false>", 4.0 * frames_step * proj_f / L, ms["proj"] / L, PEAK_F16_MFMA_TFLOPS
     achieved = flops_launch / (dur_ms * 1e-3) / 1e12
     # HBM bytes per launch of that kernel from the rocprofv3 PMC passes of this same workload (FETCH_SIZE doubled
     # per MI355X_MICROARCH.md + WRITE_SIZE); bench.py cannot collect PMC counters itself, so the committed
@@ -192,7 +192,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath) and B == B_PER_GPU:
             kk = json.load(open(tpath))["kernels"]
-            key = next((k for k in kk if k.startswith(kern.split("<")[0] if kern.startswith("lstm") else "gemm_f16p_kernel<true>")), None)
+            key = next((k for k in kk if k.startswith(kern.split("<")[0] if kern.startswith("lstm") else "gemm_f16p_kernel<false>")), None)
             if key in kk:
                 traffic, traffic_src = kk[key]["hbm_MB_per_launch"] * 1e6, "profiles/" + name
                 break
@@ -201,7 +201,7 @@ def main():
                 "traffic_source": traffic_src, "avg_launch_ms": dur_ms, "flops_per_launch": flops_launch}
     if n_fly > 1:
         roofline["note"] = ("launch duration measured while the other in-flight steps' kernels share the GPU (a recurrent launch owns "
-                            f"{B // rec_tile if rec_tile else '?'} of the 256 CUs, one workgroup of {rec_tile} sequences each; the recurrence is a serial chain, see "
+                            f"{2 * ((B + rec_tile - 1) // rec_tile) if rec_tile else '?'} of the 256 CUs, one workgroup of {rec_tile} sequences per direction each; the recurrence is a serial chain, see "
                             "DESIGN.md 3.2); see sequential.roofline for the latency-form launch with the GPU to itself")
 
     out = {

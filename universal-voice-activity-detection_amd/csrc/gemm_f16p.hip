@@ -65,7 +65,9 @@ static_assert(BM == 128 && BN == 128, "the DMA plan moves five 128-row slabs per
 
 template <bool OUT_PLANES>
 __global__ __launch_bounds__(256, UVAD_F16P_OCC) void gemm_f16p_kernel(GemmArgs a, int mt, int nt) {
-    constexpr int STAGE = KB_ELEMS, NST = UVAD_F16P_NST;   // LDS stages of one 16-deep k-block each (20 KiB)
+    // LDS stages of one 16-deep k-block each (20 KiB): a plain double buffer, three workgroups per CU hide each other's waits
+    // (rings of 3 and 4 stages with counted vmcnt waits measured the same or slower, also for the N = 128 feed-forward layers)
+    constexpr int STAGE = KB_ELEMS, NST = UVAD_F16P_NST;
     constexpr bool EPI_HALVES = NST * STAGE < BM * BN * 2;   // the f32 output tile of the blocked epilogue aliases the stages: whole, or one 128 x 64 half at a time
     constexpr int EPI_ELEMS = EPI_HALVES ? BM * GT * 2 : BM * BN * 2;
     constexpr int LDS_ELEMS = NST * STAGE > EPI_ELEMS ? NST * STAGE : EPI_ELEMS;
@@ -215,6 +217,45 @@ __global__ __launch_bounds__(256, UVAD_F16P_OCC) void gemm_f16p_kernel(GemmArgs 
             }
         }
         return;
+    }
+    if constexpr (OUT_PLANES) {
+        if (a.ldc % BN == 0) {
+            // Whole 128-column tiles of K-blocked planes: the tile's image of ONE plane -- 8 column blocks x 128 rows x 16 -- is a
+            // contiguous 32 KiB run (plane_index), rows of the padding tile included; it is assembled in LDS, one plane after the
+            // other, and leaves as 16-byte stores (2-byte stores straight from the accumulators: 0.19 ms for the 65 MB of a
+            // 256 -> 128 layer at cfg 2).
+            unsigned short *Pt = lds;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                __syncthreads();   // every wave is done reading the last stage / storing the other plane
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int lc = wc * 64 + j * 32 + fr, col = C0 + lc;
+                    const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;
+                    unsigned short *Pj = Pt + (lc >> 4) * (BM * 16) + (lc & 15);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int lr = wr * 64 + i * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+                            float v = __builtin_fmaf(__builtin_fmaf(lo[i][j][r], 0.00048828125f, hi[i][j][r]), a.wscale, bias);
+                            if (a.act == 1) v = v >= 0.f ? v : a.leaky_slope * v;
+                            if (col >= a.N) v = 0.f;   // padding columns of the consumer's K must read as zero
+                            const _Float16 h = (_Float16)v;
+                            const _Float16 piece = pl == 0 ? h : (_Float16)((v - (float)h) * 2048.0f);
+                            Pj[lr * 16] = __builtin_bit_cast(unsigned short, piece);
+                        }
+                }
+                __syncthreads();
+                unsigned short *dstp = (pl == 0 ? a.Ch : a.Cl) + ((size_t)m_tile * (a.ldc / 16) + (size_t)n_tile * (BN / 16)) * (BM * 16);
+#pragma unroll
+                for (int k = 0; k < BM * BN / 8 / 256; ++k) {
+                    const int q = tid + 256 * k;
+                    *reinterpret_cast<uint4 *>(dstp + (size_t)q * 8) = *reinterpret_cast<const uint4 *>(Pt + q * 8);
+                }
+            }
+            return;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
