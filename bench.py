@@ -182,7 +182,7 @@ def main():
         else:
             kern, flops_launch, dur_ms, peak = rec_kernel, frames_step * rec_f / L, ms["recurrent"] / L, PEAK_F32_MFMA_TFLOPS
     else:
-        kern, flops_launch, dur_ms, peak = "gemm_f16p_kernel<false>", 4.0 * frames_step * proj_f / L, ms["proj"] / L, PEAK_F16_MFMA_TFLOPS
+        kern, flops_launch, dur_ms, peak = "gemm_f16p_kernel<false, 2>", 4.0 * frames_step * proj_f / L, ms["proj"] / L, PEAK_F16_MFMA_TFLOPS
     achieved = flops_launch / (dur_ms * 1e-3) / 1e12
     # HBM bytes per launch of that kernel from the rocprofv3 PMC passes of this same workload (FETCH_SIZE doubled
     # per MI355X_MICROARCH.md + WRITE_SIZE); bench.py cannot collect PMC counters itself, so the committed
@@ -192,13 +192,18 @@ def main():
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath) and B == B_PER_GPU:
             kk = json.load(open(tpath))["kernels"]
-            key = next((k for k in kk if k.startswith(kern.split("<")[0] if kern.startswith("lstm") else "gemm_f16p_kernel<false>")), None)
+            key = next((k for k in kk if k.startswith(kern.split("<")[0] if kern.startswith("lstm") else "gemm_f16p_kernel<false")), None)
             if key in kk:
                 traffic, traffic_src = kk[key]["hbm_MB_per_launch"] * 1e6, "profiles/" + name
                 break
     roofline = {"kernel": kern, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch",
                 "traffic_source": traffic_src, "avg_launch_ms": dur_ms, "flops_per_launch": flops_launch}
+    # all MFMA work of a step (projections, recurrence and feed-forward: four f16 products per f32-equivalent product) over the step
+    # time: what the chip's f16 matrix pipe delivers with the steps in flight, independent of how launches overlap
+    step_tf = 4.0 * frames_step * (proj_f + rec_f + head_f) / (elapsed / args.steps) / 1e12 if rec_tile == 16 else None
+    if step_tf is not None:
+        roofline["whole_step_f16_pipe"] = {"achieved": step_tf, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": step_tf / PEAK_F16_MFMA_TFLOPS}
     if n_fly > 1:
         roofline["note"] = ("launch duration measured while the other in-flight steps' kernels share the GPU (a recurrent launch owns "
                             f"{2 * ((B + rec_tile - 1) // rec_tile) if rec_tile else '?'} of the 256 CUs, one workgroup of {rec_tile} sequences per direction each; the recurrence is a serial chain, see "
@@ -250,19 +255,27 @@ def sequential_latency(rt, dev, pcm, steps, world, forced=0):
     frames = world * pcm.shape[0] * rt.num_frames(pcm.shape[1]) * steps
     # the recurrent kernel's launch duration when it has the GPU to itself (3 more steps with stage events)
     rt.set_timing(True)
-    rec = 0.0
+    rec = proj = 0.0
     for _ in range(3):
         rt.forward(pcm, want_probs=False)
-        rec += rt.timing_ms()["recurrent"]
+        tm = rt.timing_ms()
+        rec += tm["recurrent"]
+        proj += tm["proj"]
     rt.set_timing(False)
     used = rt.recurrent_tile()
     rt.set_recurrent_tile(forced)
-    _, rec_f, _ = classifier_flops_per_frame(N_MELS)
+    proj_f, rec_f, _ = classifier_flops_per_frame(N_MELS)
     launch_ms = rec / 3 / 4
     tf = pcm.shape[0] * rt.num_frames(pcm.shape[1]) * rec_f / 4 / (launch_ms * 1e-3) / 1e12
+    proj_ms = proj / 3 / 4
+    ptf = 4.0 * pcm.shape[0] * rt.num_frames(pcm.shape[1]) * proj_f / 4 / (proj_ms * 1e-3) / 1e12
     return {"value": frames / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps_in_flight": 1, "recurrent_tile": used,
             "roofline": {"kernel": "lstm_rec_kernel<128, 8, true>", "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": launch_ms},
+            "projection_roofline": {"kernel": "gemm_f16p_kernel<false, 2>", "bound": "mfma", "achieved": ptf, "peak": PEAK_F16_MFMA_TFLOPS,
+                                    "unit": "TFLOP/s", "frac": ptf / PEAK_F16_MFMA_TFLOPS, "avg_launch_ms": proj_ms,
+                                    "note": "f16-pipe rate (4 MFMA products per f32-equivalent product), the launch alone on the GPU; average of the "
+                                            "K = 64 and the three K = 256 projections"},
             "note": "same step, one at a time on one stream; not the headline value"}
 
 

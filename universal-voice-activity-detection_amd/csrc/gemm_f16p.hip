@@ -63,11 +63,14 @@ static_assert(BM == 128 && BN == 128, "the DMA plan moves five 128-row slabs per
 #define UVAD_F16P_OCC 3
 #endif
 
-template <bool OUT_PLANES>
-__global__ __launch_bounds__(256, UVAD_F16P_OCC) void gemm_f16p_kernel(GemmArgs a, int mt, int nt) {
-    // LDS stages of one 16-deep k-block each (20 KiB): a plain double buffer, three workgroups per CU hide each other's waits
-    // (rings of 3 and 4 stages with counted vmcnt waits measured the same or slower, also for the N = 128 feed-forward layers)
-    constexpr int STAGE = KB_ELEMS, NST = UVAD_F16P_NST;
+template <bool OUT_PLANES, int NSTAGES>
+__global__ __launch_bounds__(256, NSTAGES == 2 ? UVAD_F16P_OCC : 1) void gemm_f16p_kernel(GemmArgs a, int mt, int nt) {
+    // LDS stages of one 16-deep k-block each (20 KiB).  NSTAGES = 2, the throughput instance: a plain double buffer, three
+    // workgroups per CU hide each other's waits (rings of 3 and 4 stages with counted vmcnt waits measured the same or slower,
+    // also for the N = 128 feed-forward layers).  NSTAGES = 4, the latency instance for launches that do not fill the chip
+    // (the per-chunk steps of uvad_stream_step: 64 workgroups at 512 feeds): three k-blocks in flight per workgroup, because
+    // there the K loop is a chain of L2 / HBM round trips with nothing else on the CU to cover them.
+    constexpr int STAGE = KB_ELEMS, NST = NSTAGES;
     constexpr bool EPI_HALVES = NST * STAGE < BM * BN * 2;   // the f32 output tile of the blocked epilogue aliases the stages: whole, or one 128 x 64 half at a time
     constexpr int EPI_ELEMS = EPI_HALVES ? BM * GT * 2 : BM * BN * 2;
     constexpr int LDS_ELEMS = NST * STAGE > EPI_ELEMS ? NST * STAGE : EPI_ELEMS;
@@ -372,10 +375,11 @@ hipError_t launch_gemm_f16p(const GemmArgs &a, hipStream_t s) {
     if (a.c_blocked && (a.out_planes || a.act != 0 || a.N % BN != 0)) return hipErrorInvalidValue;   // the gate matrix: whole 128-column tiles, no activation
     const int mt = (a.M + BM - 1) / BM, nt = ((a.out_planes ? a.ldc : a.N) + BN - 1) / BN;
     const int grid = ((mt + 7) / 8) * 8 * nt;
-    if (a.out_planes)
-        hipLaunchKernelGGL((gemm_f16p_kernel<true>), dim3(grid), dim3(256), 0, s, a, mt, nt);
-    else
-        hipLaunchKernelGGL((gemm_f16p_kernel<false>), dim3(grid), dim3(256), 0, s, a, mt, nt);
+    const bool small = (long)mt * nt <= 512;   // fewer than two workgroups per CU of an MI355X: latency instance
+    if (a.out_planes && small) hipLaunchKernelGGL((gemm_f16p_kernel<true, 4>), dim3(grid), dim3(256), 0, s, a, mt, nt);
+    else if (a.out_planes) hipLaunchKernelGGL((gemm_f16p_kernel<true, UVAD_F16P_NST>), dim3(grid), dim3(256), 0, s, a, mt, nt);
+    else if (small) hipLaunchKernelGGL((gemm_f16p_kernel<false, 4>), dim3(grid), dim3(256), 0, s, a, mt, nt);
+    else hipLaunchKernelGGL((gemm_f16p_kernel<false, UVAD_F16P_NST>), dim3(grid), dim3(256), 0, s, a, mt, nt);
     return hipGetLastError();
 }
 
