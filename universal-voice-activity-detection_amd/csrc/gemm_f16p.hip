@@ -21,21 +21,24 @@
 //   and the exact-f32 kernel of gemm.hip runs the first projection instead, GemmArgs::gate).
 //
 // gfx950 design (HBM-bound on paper: 1.05 GB of gate pre-activations written per K = 256 projection at cfg 2)
-//   * 128 x 64 output tile per 256-thread workgroup (4 waves as 2 x 2, each 64 x 32 = two 32x32 MFMA tiles x two accumulator
-//     sets = 64 accumulator registers): ~110 VGPRs, so FOUR workgroups share a CU and hide each other's barriers and
-//     memory latency -- occupancy instead of a deep software pipeline.
+//   * 128 x 128 output tile per 256-thread workgroup (4 waves as 2 x 2, each 64 x 64 = four 32x32 MFMA tiles x two accumulator
+//     sets = 128 accumulator registers): ~162 VGPRs, so THREE workgroups share a CU and hide each other's barriers and
+//     memory latency -- occupancy instead of a deep software pipeline.  The kernel is bound by the operand stream through the
+//     vector memory path (L2 -> LDS), not by the matrix pipe: the first version's 128 x 64 tile moved 14 KiB per 32 MFMAs,
+//     this one 20 KiB per 64 (ablations and counters: DESIGN.md section 3.3).
 //   * All five operand planes of a K-step go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
 //     VALU), double buffered: one barrier per K-step, the next step's loads are in flight during this step's MFMAs.
 //   * Planes live in HBM in a K-BLOCKED layout (plane_index() in uvad_internal.h): [row tile][16-column block][row][16], so
-//     the slab a workgroup needs for one 16-deep k-block of one plane is ONE contiguous 4 KiB (A, 128 rows) / 2 KiB (W, 64
-//     rows) run and every DMA wave-instruction reads eight full 128-byte lines.  (Row-major planes were measured first:
-//     a K-step then touches 32-byte pieces of rows 512 bytes apart, 32 L2 requests per wave-instruction, and the kernel is
-//     bound by the L2 request rate -- TA busy 77 %, MFMA busy 21 %, profiles/README.md.)
+//     the slab a workgroup needs for one 16-deep k-block of one plane is ONE contiguous 4 KiB run (128 rows) and every DMA
+//     wave-instruction reads eight full 128-byte lines.  (Row-major planes were measured first: a K-step then touches
+//     32-byte pieces of rows 512 bytes apart, 32 L2 requests per wave-instruction, and the kernel is bound by the L2
+//     request rate -- TA busy 77 %, MFMA busy 21 %, profiles/README.md.)
 //   * The LDS image is dense (a DMA wave-instruction writes 1 KiB contiguously); bank conflicts of the ds_read_b128
 //     fragment reads are removed by an XOR swizzle of the 16-byte chunk index applied to the DMA's per-lane SOURCE
 //     address and to the read address (cdna_hip_programming.md section 5.4 rule 21).
-//   * The epilogue stores straight from the accumulators: the 32x32 C layout gives each store instruction two full 128-byte
-//     row segments (measured in round 1: staging the tile through LDS for 16-byte stores moved no time).
+//   * Epilogue: the tile is assembled in LDS (over the operand stages) and leaves as unmasked 16-byte stores into its
+//     contiguous run of the blocked gate matrix / of the K-blocked output planes (dword stores straight from the 32x32 C
+//     layout reached 2.9 TB/s and did not overlap the K loops of the other workgroups).
 //   * Block ids are remapped so that the N-tiles sharing one A row panel run on the same XCD (private L2) back to back.
 #include "uvad_internal.h"
 
