@@ -211,9 +211,10 @@ int uvad_forward_wav(uvad_ctx *, const float *d_wav, int B, int64_t S, float *d_
 
 /* Which kernel runs the time-parallel contractions (input projections, feed-forward layers):
  *   0  exact f32: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain, bit-compatible with f32 FMA arithmetic;
- *   1  (default) f32-accurate on the f16 matrix cores: operands split into two f16 pieces (the low one scaled by
- *      2^11), three v_mfma_f32_32x32x16_f16 per product term set in two f32 accumulator sets (dropped term
- *      <= 2^-22 relative, below the rounding noise of the f32 accumulation).
+ *   1  (default) f32-accurate on the f16 matrix cores: weights scaled by a power of two and split on the host into THREE
+ *      f16 planes that reproduce them exactly, activations into two planes (22 bits) by the kernel that produces them;
+ *      four v_mfma_f32_32x32x16_f16 products per term set in two f32 accumulator sets (dropped terms <= 2^-22 relative,
+ *      below the rounding noise of the f32 accumulation).
  *      Needs operands inside the f16 range (|x| < 65504).  The library guarantees that without the caller's help:
  *      weights (and the bound they put on the feed-forward activations) are checked by uvad_finalize and a context
  *      that fails runs mode 0; features handed to uvad_classify are checked on the device and a batch that fails runs
@@ -223,7 +224,9 @@ int uvad_set_gemm_mode(uvad_ctx *, int mode);
 
 /* How many sequences one recurrent workgroup owns (the time loop of nn.LSTM, PyanNet2.py:169-172):
  *   4   latency form (v_mfma_f32_4x4x1): B/4 x directions workgroups, the right one up to a few hundred sequences;
- *   16  throughput form (v_mfma_f32_16x16x4, hidden_size 128 only): fewer, heavier workgroups for B >= 1024;
+ *   16  throughput form (hidden_size 128 only): W_hh * h as four v_mfma_f32_16x16x32_f16 products on the same exact
+ *       three-plane split as GEMM mode 1; a quarter of the workgroups, each 1.4 x as long: a third of the CU-time per
+ *       sequence.  The right one for B >= 1024 and for callers that keep several batches in flight on separate contexts;
  *   0   (default) chosen per call: the form with fewer estimated rounds of workgroups over the CUs (uvad_recurrent_tile_for).
  * uvad_get_recurrent_tile returns what the most recent uvad_classify / uvad_forward* call launched (4 or 16; 0 before
  * the first call).  Results agree to rounding between the two (tests/test_gpu_parity.py). */

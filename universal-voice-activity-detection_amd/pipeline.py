@@ -1,14 +1,16 @@
 """ForwardPipeline: keep several uvad_forward calls in flight.
 
-Why: at the reference's batch sizes the recurrent kernel is a latency-bound chain that occupies only B/4 x directions
-of the 256 CUs (128 at B = 256); a second, independent batch submitted on another HIP stream runs its feature kernel and
-projections on the idle CUs (bench.py: 32 -> 44 M frames/s at BASELINE cfg 2).  Each slot is a full VadRuntime
-(own weights copy and workspace) bound to its own stream; results are identical to the sequential path (same kernels,
-same launch shapes).
+Why: the recurrence of one batch is a serial chain of 4 x T steps that cannot use the chip -- at B = 256 its latency form
+occupies 128 of the 256 CUs for 5.3 ms, its throughput form (recurrent_tile=16) 32 CUs for 7.4 ms.  Independent batches
+submitted on other HIP streams run their feature kernels, projections and recurrences on the CUs one batch leaves idle
+(bench.py at BASELINE cfg 2: 33 M frames/s one step at a time, 66 M with eight in flight and the throughput form).  Each slot is
+a full VadRuntime (own weights copy and workspace) bound to its own stream; results are identical to the sequential path with
+the same recurrent form (same kernels, same launch shapes).
 
-Stream choice: HIP maps streams onto a small pool of hardware queues and two streams that land on one queue serialise.
-``select_streams`` therefore creates streams until ``depth`` of them are PROVEN pairwise concurrent by
-``uvad_streams_overlap`` (a spinning wave on one, an empty kernel on the other): an observation made once at
+Stream choice: HIP maps streams onto a small pool of hardware queues (four by default; the HIP runtime reads
+GPU_MAX_HW_QUEUES when it starts, so a caller that wants depth > 4 sets it before the first HIP call) and streams that
+land on one queue serialise.  ``select_streams`` therefore creates streams until ``depth`` of them are PROVEN pairwise
+concurrent by ``uvad_streams_overlap`` (a spinning wave on one, an empty kernel on the other): an observation made once at
 construction, not a timing heuristic."""
 from typing import List, Optional
 
