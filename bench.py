@@ -95,7 +95,7 @@ def main():
     # order of INDEPENDENT steps changes.  The recurrence is a serial chain of 4 x T steps that cannot use the whole chip for
     # one batch: in its throughput form (16 sequences per workgroup, --rec-tile 16) a batch of 256 occupies 32 CUs for ~2 ms
     # per layer, and the other steps' feature kernels, projections and recurrences run on the rest.  --in-flight 1 = sequential.
-    n_fly = max(1, min(args.in_flight, 8))
+    n_fly = max(1, min(args.in_flight, 16))
     pipe = uvad_amd.ForwardPipeline(model, dev, depth=n_fly, recurrent_tile=args.rec_tile)
     rts = pipe.runtimes
     rt = rts[0]

@@ -585,6 +585,33 @@ def test_tile16_throughput_kernel_matches_tile4():
     assert d < LOGIT_TOL
 
 
+@pytest.mark.parametrize("B,T,bidir,fc", [(40, 37, True, 2), (1, 1, True, 2), (33, 2, True, 2), (64, 129, False, 2), (17, 300, True, 0),
+                                         (32, 50, True, 0), (64, 129, False, 0), (17, 3, True, 0)])
+def test_recurrent_forms_agree_on_ragged_shapes(B, T, bidir, fc):
+    """4- and 16-sequence recurrent kernels on batches that are not multiples of either tile, frame counts around the 128-row
+    blocks of the gate matrix, one direction, and the last LSTM layer's exact-f32 output (no feed-forward layers): they agree to
+    rounding, and each is bit-reproducible run to run (the kernels keep no branch between an MFMA and the read of its result)."""
+    import uvad_amd
+    from uvad_amd.synth import seed_weights
+    dev = torch.device("cuda:0")
+    m = uvad_amd.PyanNet2(encoding_dim=64, lstm={"bidirectional": bidir}, linear={"num_layers": fc})
+    m.build()
+    seed_weights(m, 1234, 2.0)
+    m = m.to(dev).eval()
+    rt = m.runtime(dev)
+    x = torch.randn(B, T, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(B * 1000 + T)) * 3
+    outs = {}
+    for tile in (4, 16):
+        rt.set_recurrent_tile(tile)
+        runs = [rt.classify(x, want_probs=False)[0].clone() for _ in range(3)]
+        assert rt.recurrent_tile() == tile
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), f"tile {tile} differs run to run"
+        outs[tile] = runs[0]
+    rt.set_recurrent_tile(0)
+    d = float((outs[4] - outs[16]).abs().max())
+    assert torch.isfinite(outs[16]).all() and d < 1e-5, d
+
+
 def test_forward_pipeline_results_equal_sequential_path():
     """uvad_amd.ForwardPipeline (several uvad_forward calls in flight on HIP streams proven concurrent by uvad_streams_overlap): every batch's logits are
     bit-identical to the ones the plain sequential path produces, whatever slot ran them."""
@@ -603,6 +630,17 @@ def test_forward_pipeline_results_equal_sequential_path():
     got = [p.result()[0] for p in pend]
     assert pipe.streams is not None and len(pipe.streams) == 2 and pipe.streams[0] != pipe.streams[1]
     for w, g in zip(want, got):
+        assert torch.equal(w, g)
+    pipe.close()
+    # the throughput form of the recurrence in every slot (what bench.py runs): same bits as that form one call at a time
+    rt = m.runtime(dev)
+    rt.set_recurrent_tile(16)
+    want16 = [m.forward_waveform(b)[0].clone() for b in batches]
+    rt.set_recurrent_tile(0)
+    pipe = uvad_amd.ForwardPipeline(m, dev, depth=4, recurrent_tile=16)
+    got16 = [p.result()[0] for p in [pipe.submit(b) for b in batches]]
+    assert all(r.recurrent_tile() == 16 for r in pipe.runtimes)
+    for w, g in zip(want16, got16):
         assert torch.equal(w, g)
     pipe.close()
     with pytest.raises(RuntimeError, match="attach_fbank"):

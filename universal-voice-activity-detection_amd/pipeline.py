@@ -34,7 +34,7 @@ class Pending:
 
 
 class ForwardPipeline:
-    MAX_STREAM_TRIES = 16
+    MAX_STREAM_TRIES = 48
 
     def __init__(self, model, device, depth: int = 2, recurrent_tile: int = 0):
         """model: a built uvad_amd.PyanNet2 with attach_fbank(...) done (weights are copied into every slot).
