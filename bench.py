@@ -96,7 +96,15 @@ def main():
     # one batch: in its throughput form (16 sequences per workgroup, --rec-tile 16) a batch of 256 occupies 32 CUs for ~2 ms
     # per layer, and the other steps' feature kernels, projections and recurrences run on the rest.  --in-flight 1 = sequential.
     n_fly = max(1, min(args.in_flight, 16))
-    pipe = uvad_amd.ForwardPipeline(model, dev, depth=n_fly, recurrent_tile=args.rec_tile)
+    pipe = None
+    while pipe is None:   # a device / runtime that offers fewer concurrent hardware queues than asked for: fewer steps in flight, not a failure
+        try:
+            pipe = uvad_amd.ForwardPipeline(model, dev, depth=n_fly, recurrent_tile=args.rec_tile)
+        except RuntimeError as e:
+            if n_fly == 1 or "concurrent HIP streams" not in str(e):
+                raise
+            log(f"{e}; continuing with {n_fly // 2} step(s) in flight")
+            n_fly //= 2
     rts = pipe.runtimes
     rt = rts[0]
     pcm = synth_pcm_device(B, S, seed=42, device=dev, first=rank * B)   # disjoint utterance ids per rank

@@ -56,7 +56,11 @@ class ForwardPipeline:
         self.streams: Optional[List[torch.cuda.Stream]] = None
         self.streams_tried = 0
         self._k = 0
-        self.select_streams()
+        try:
+            self.select_streams()
+        except Exception:
+            self.close()   # the slots hold device memory: do not leave them behind a failed construction
+            raise
 
     # ------------------------------------------------------------------ streams
     def select_streams(self) -> List[torch.cuda.Stream]:
