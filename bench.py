@@ -9,7 +9,7 @@ reference) on the named frame shape.
 Workload (config.workload = BASELINE configs[1]): per GPU, B=256 utterances x 10 s of synthetic
 16 kHz audio, 25 ms / 10 ms frames, 64-bin log-mel (Hamming) + PyanNet2 classifier; a "step" is
 one pass of the whole hot path (uvad_forward: PCM resident in HBM -> per-frame logits in HBM) over
-that batch.  The K steps are submitted round-robin to eight contexts / HIP streams (eight steps in flight, the recurrence in
+that batch.  The K steps are submitted round-robin to twelve contexts / HIP streams (twelve steps in flight, the recurrence in
 its throughput form; every step does all of its work, see main()); --in-flight 1 --rec-tile 0 submits them strictly one after
 the other with the library's latency-optimal choices (reported as the extra object "sequential").  N GPUs = N independent shards of 256 utterances (weak scaling, no data-path
 collective; utterance ids are disjoint across ranks).  value = frames all ranks processed / max
@@ -31,7 +31,7 @@ import time
 
 # HIP maps streams onto a small pool of hardware queues (4 by default) and streams that share a queue serialise: the steps kept
 # in flight need one queue each.  Must be set before the HIP runtime starts (i.e. before torch is imported).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import torch
 
@@ -58,11 +58,11 @@ def classifier_flops_per_frame(F, H=128, L=4, D=2, lin=128, lin_layers=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="utterances per GPU (default = BASELINE cfg 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=8, help="steps in flight (1 = strictly sequential submission, 8 = default)")
+    ap.add_argument("--in-flight", type=int, default=12, help="steps in flight (1 = strictly sequential submission, 12 = default)")
     ap.add_argument("--rec-tile", type=int, default=16, choices=[0, 4, 16],
                     help="recurrent form of the in-flight contexts: 0 = the library's per-call choice, 4 = latency form, 16 = throughput form")
     ap.add_argument("--no-sequential", action="store_true", help="skip the extra strictly sequential measurement")
