@@ -131,12 +131,15 @@ def main():
     torch.cuda.synchronize(dev)
     udist.barrier()
     t0 = time.perf_counter()
+    recent = []
     for k in range(args.steps):
         if k >= n_fly and live_events:   # stage times of the step this context ran last (waits for THAT step only; the other is in flight)
             for name, v in rts[pipe.slot_of_next_submit()].timing_ms().items():
                 acc[name] += v
             n_acc += 1
-        pending = submit(k)
+        recent.append(submit(k))
+        if len(recent) > n_fly:
+            recent.pop(0)
     torch.cuda.synchronize(dev)
     udist.barrier()
     elapsed = time.perf_counter() - t0
@@ -146,10 +149,17 @@ def main():
         n_acc += 1
     for r in rts:
         r.set_timing(False)
+    # Outside the timed region: every step processed the same batch, so the logits of the last n_fly steps (one per slot, all
+    # produced while the others were in flight) must equal, bit for bit, what one call alone produces.  Concurrent kernels
+    # corrupting each other would show here (tools/pipe_check.py is the longer version of this check).
+    alone = rts[0].forward(pcm, want_probs=False)[0]
+    torch.cuda.synchronize(dev)
+    n_wrong = sum(int(not torch.equal(p.result()[0], alone)) for p in recent)
+    del recent, alone
     elapsed = udist.max_over_ranks(elapsed, device=dev if world > 1 else None)
     log(f"{args.steps} steps in {elapsed:.3f} s")
     if not live_events:
-        log(f"diagnostic run without stage events: {world * B * T * args.steps / elapsed / 1e6:.2f} M frames/s")
+        log(f"diagnostic run without stage events: {world * B * T * args.steps / elapsed / 1e6:.2f} M frames/s ({n_wrong} wrong outputs)")
         return
 
     frames_total = world * B * T * args.steps
@@ -228,6 +238,7 @@ def main():
         "roofline": roofline, "stages": stage,
         "classifier_f32_equivalent_TFLOPs": frames_step * (proj_f + rec_f + head_f) / (elapsed / args.steps) / 1e12,
     }
+    out["in_flight_outputs_identical_to_single_call"] = n_wrong == 0
     out["config"]["steps_in_flight"] = n_fly
     out["config"]["recurrent_tile"] = rts[0].recurrent_tile()
     out["stages_note"] = ("per-stage HIP-event times of one step, measured inside the timed region on that step's own stream; with several steps "
@@ -244,6 +255,8 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     udist.barrier()
+    if n_wrong:
+        raise SystemExit(f"bench.py: {n_wrong} of the last {n_fly} in-flight steps differ from a single call: the result is invalid")
 
 
 def sequential_latency(rt, dev, pcm, steps, world, forced=0):

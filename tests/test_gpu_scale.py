@@ -194,3 +194,20 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
     sc = d["scatter"]
     assert sc["global_batch"] == 64 and sc["scatter_ms"] > 0 and sc["frames_per_s_with_scatter"] > 0 and "gloo" in sc["backend"]
     print("2-rank rehearsal:", {k: d[k] for k in ("value", "ms_per_step")}, sc)
+
+
+def test_bench_regime_outputs_identical_to_single_calls():
+    """The headline regime checked for CORRECTNESS, not speed: twelve steps of the cfg-2 batch in flight on twelve hardware queues with
+    the throughput recurrence (tools/pipe_check.py in its own process, because the queue count is fixed when HIP starts): every
+    step's logits equal a single call's bit for bit.  (A 128x128-tile build of the split-f16 GEMM failed this in 80 of 96 steps --
+    its workgroups corrupted the feature kernel's frames when they shared CUs -- while every single-stream test stayed green.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "pipe_check.py"), "--steps", "96", "--depth", "12"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert line, out.stderr[-2000:]
+    d = json.loads(line[-1])
+    print(d)
+    assert out.returncode == 0 and d["steps_with_wrong_logits"] == 0, d
