@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""fbank_kernel beside a synthetic MFMA burner (tools/mfma_burner.hip): python tools/burner_probe.py"""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import uvad_amd
+from uvad_amd.synth import seed_weights, synth_pcm_device
+dev = torch.device("cuda:0")
+lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libburner.so"))
+lib.burner_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+m = uvad_amd.PyanNet2(encoding_dim=64); m.build(); seed_weights(m, 1234, 4.0)
+m.attach_fbank(uvad_amd.FbankConfig(num_filters=64, window_type="hamming")); m = m.to(dev).eval()
+rt = m.runtime(dev)
+pcm = synth_pcm_device(256, 160000, seed=42, device=dev)
+want = rt.fbank(pcm).clone()
+sink = torch.empty(8192 * 256, device=dev)
+sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+assert rt.streams_overlap(sa, sb), "streams share a queue: rerun"
+feats = want
+x = torch.randn(64 * 1024 * 1024 // 4, device=dev)
+victims = {
+    "fbank": lambda: rt.fbank(pcm),
+    "classify": lambda: rt.classify(feats, want_probs=False)[0],
+    "torch.sin": lambda: torch.sin(x),
+    "torch.fft.rfft": lambda: torch.view_as_real(torch.fft.rfft(x.view(-1, 512))),
+}
+A16 = torch.randn(8192, 8192, device=dev, dtype=torch.float16)
+B16 = torch.randn(8192, 8192, device=dev, dtype=torch.float16)
+def aggressor(kind):
+    if kind == "burner": lib.burner_launch(0, sink.data_ptr(), 8192, 400, sb.cuda_stream)
+    elif kind == "matmul": torch.matmul(A16, B16)       # the stock f16 GEMM of the installed BLAS (MFMA + LDS + barriers)
+for vname, fn in victims.items():
+    ref = fn().clone()
+    torch.cuda.synchronize(dev)
+    for kind in ("none", "burner", "matmul"):
+        bad = 0
+        for rep in range(30):
+            with torch.cuda.stream(sb):
+                aggressor(kind)
+            with torch.cuda.stream(sa):
+                outs = [fn() for _ in range(3)]
+            torch.cuda.synchronize(dev)
+            bad += sum(int(not torch.equal(o, ref)) for o in outs)
+        print(f"victim {vname} beside '{kind}': {bad} wrong of 90")
