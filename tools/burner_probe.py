@@ -4,6 +4,8 @@ import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import uvad_amd
+from uvad_amd import _lib
+if len(sys.argv) > 1 and sys.argv[1].endswith('.so'): _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 from uvad_amd.synth import seed_weights, synth_pcm_device
 dev = torch.device("cuda:0")
 lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libburner.so"))
@@ -29,7 +31,9 @@ B16 = torch.randn(8192, 8192, device=dev, dtype=torch.float16)
 def aggressor(kind):
     if kind == "burner": lib.burner_launch(0, sink.data_ptr(), 8192, 400, sb.cuda_stream)
     elif kind == "matmul": torch.matmul(A16, B16)       # the stock f16 GEMM of the installed BLAS (MFMA + LDS + barriers)
+only = [a for a in sys.argv[1:] if not a.endswith('.so')]
 for vname, fn in victims.items():
+    if only and vname not in only: continue
     ref = fn().clone()
     torch.cuda.synchronize(dev)
     for kind in ("none", "burner", "matmul"):

@@ -14,9 +14,11 @@
 //     complex FFT, 8 points per lane, as three radix-8 passes (512 = 8*8*8) held in registers;
 //     the two re-distributions between passes go through a padded per-wave LDS scratch with
 //     wave-local ordering only (no workgroup barrier in the loop).
-//   * the two spectra are separated with the conjugate-symmetry identity, |.|^2 goes to LDS as
-//     (frameA, frameB) pairs (over the transpose scratch), and lane m accumulates mel filter m over its
-//     (start,len) band, two bins per LDS instruction; 64 lanes write 256 contiguous bytes per frame.
+//   * the two spectra are separated with the conjugate-symmetry identity, |.|^2 of frame A and of frame B go to LDS
+//     (over the transpose scratch), and lane m accumulates mel filter m over its (start,len) band, two bins per
+//     iteration; 64 lanes write 256 contiguous bytes per frame.
+//   * every LDS access is a 32-bit operation (real and imaginary parts live in separate arrays): see the note at the
+//     per-wave scratch in the kernel.
 //   The kernel is bound by vector-instruction issue, not by HBM: ~650 instructions per lane and frame pair
 //   (three radix-8 passes, two transposes, framing, mel) put the ceiling near 1.5 G frames/s = 17 % of the
 //   8.9 G frames/s the HBM roofline would allow.
@@ -235,8 +237,15 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
     __syncthreads();
 
     FB_STAMP(0)   // [0] tile staging + per-lane constants
-    float2 *zb = wscr + (size_t)wave * (ZB_ELEMS + PB_ELEMS);
-    float2 *pb = zb;   // written only after every spectrum value of the pair has been read into registers
+    // Per-wave scratch as TWO 4-byte arrays (real / imaginary parts of the transform; later the power of frame A / frame B), never
+    // as float2 pairs: every LDS instruction of this kernel is a 32-bit one (ds_read_b32 / ds_read2_b32 / ds_write2_b32 ...).
+    // With 64-bit LDS operations (ds_read_b64, ds_write2st64_b64, ...) the kernel returned wrong frames whenever its waves
+    // shared a CU with waves of another kernel that loop over MFMAs, an LDS read and s_barrier (a GEMM of another step in
+    // flight) -- the same happens to stock rocFFT, and the 32-bit form is immune (DESIGN.md section 3.3,
+    // profiles/r02_concurrency_corruption.json).  It is also 3 % faster.
+    float *zr = reinterpret_cast<float *>(wscr + (size_t)wave * (ZB_ELEMS + PB_ELEMS)), *zi = zr + ZB_ELEMS;
+#define ZB_PUT(idx, a, b) { zr[idx] = (a); zi[idx] = (b); }
+#define ZB_GET(idx) make_float2(zr[idx], zi[idx])
     const float inv_len = 1.0f / (float)L;
 
     for (int q = 0; q < PAIRS_PER_WAVE; ++q) {
@@ -289,12 +298,12 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
         {
             const int aa = lane >> 3, bb = lane & 7;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) zb[(k * 8 + bb) * ZB_LD + aa] = make_float2(re[k], im[k]);
+            for (int k = 0; k < 8; ++k) ZB_PUT((k * 8 + bb) * ZB_LD + aa, re[k], im[k]);
         }
         wave_lds_fence();
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float2 v = zb[lane * ZB_LD + k];
+            const float2 v = ZB_GET(lane * ZB_LD + k);
             re[k] = v.x; im[k] = v.y;
         }
         FB_STAMP(2)   // [2] pass 1 + transpose
@@ -310,12 +319,12 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
         {
             const int k1 = lane >> 3, bb = lane & 7;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) zb[(k1 * 8 + c) * ZB_LD + bb] = make_float2(re[c], im[c]);
+            for (int c = 0; c < 8; ++c) ZB_PUT((k1 * 8 + c) * ZB_LD + bb, re[c], im[c]);
         }
         wave_lds_fence();
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float2 v = zb[lane * ZB_LD + k];
+            const float2 v = ZB_GET(lane * ZB_LD + k);
             re[k] = v.x; im[k] = v.y;
         }
         FB_STAMP(3)   // [3] pass 2 + transpose
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
         {
             const int lam = (lane >> 3) + 8 * (lane & 7);
 #pragma unroll
-            for (int d = 0; d < 8; ++d) zb[lam + 64 * d] = make_float2(re[d], im[d]);
+            for (int d = 0; d < 8; ++d) ZB_PUT(lam + 64 * d, re[d], im[d]);
         }
         wave_lds_fence();
         FB_STAMP(4)   // [4] pass 3 + spectrum to LDS
@@ -337,8 +346,8 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
             for (int d = 0; d < 5; ++d) {
                 const int k = lane + 64 * d;
                 const int kc = d < 4 ? k : (lane == 0 ? 256 : 0);
-                const float2 z = zb[kc];
-                const float2 w = zb[(NFFT - kc) & (NFFT - 1)];
+                const float2 z = ZB_GET(kc);
+                const float2 w = ZB_GET((NFFT - kc) & (NFFT - 1));
                 const float ar = z.x + w.x, ai = z.y - w.y;
                 const float br = z.y + w.y, bi = z.x - w.x;
                 pw[d] = make_float2(0.25f * (ar * ar + ai * ai), 0.25f * (br * br + bi * bi));
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
             wave_lds_fence();
 #pragma unroll
             for (int d = 0; d < 5; ++d)
-                if (d < 4 || lane == 0) pb[lane + 64 * d] = pw[d];
+                if (d < 4 || lane == 0) ZB_PUT(lane + 64 * d, pw[d].x, pw[d].y);
         }
         wave_lds_fence();
         FB_STAMP(5)   // [5] split + power
@@ -361,10 +370,9 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
             const int st = ps == 0 ? mst0v : mst1;   // n_mels <= 128 (checked by uvad_create): no global load in this loop
             float ea = 0.f, eb = 0.f, ea2 = 0.f, eb2 = 0.f;
             const float *wp = melw + mm;
-            const float2 *pp = pb + st;
             for (int i = 0; i < mel_pairs; ++i) {
                 const float w0 = wp[(2 * i) * F], w1 = wp[(2 * i + 1) * F];
-                const float2 p0 = pp[2 * i], p1 = pp[2 * i + 1];
+                const float2 p0 = ZB_GET(st + 2 * i), p1 = ZB_GET(st + 2 * i + 1);
                 ea = __builtin_fmaf(w0, p0.x, ea);
                 eb = __builtin_fmaf(w0, p0.y, eb);
                 ea2 = __builtin_fmaf(w1, p1.x, ea2);

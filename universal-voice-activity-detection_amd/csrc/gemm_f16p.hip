@@ -21,21 +21,24 @@
 //   and the exact-f32 kernel of gemm.hip runs the first projection instead, GemmArgs::gate).
 //
 // gfx950 design (HBM-bound on paper: 1.05 GB of gate pre-activations written per K = 256 projection at cfg 2)
-//   * 128 x 64 output tile per 256-thread workgroup (4 waves as 2 x 2, each 64 x 32 = two 32x32 MFMA tiles x two accumulator
-//     sets = 64 accumulator registers): ~110 VGPRs, so FOUR workgroups share a CU and hide each other's barriers and
-//     memory latency -- occupancy instead of a deep software pipeline.
+//   * 128 x 128 output tile per 256-thread workgroup (4 waves as 2 x 2, each 64 x 64 = four 32x32 MFMA tiles x two accumulator
+//     sets = 128 accumulator registers): ~162 VGPRs, so THREE workgroups share a CU and hide each other's barriers and
+//     memory latency -- occupancy instead of a deep software pipeline.  The kernel is bound by the operand stream through the
+//     vector memory path (L2 -> LDS), not by the matrix pipe: the first version's 128 x 64 tile moved 14 KiB per 32 MFMAs,
+//     this one 20 KiB per 64 (ablations and counters: DESIGN.md section 3.3).
 //   * All five operand planes of a K-step go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
 //     VALU), double buffered: one barrier per K-step, the next step's loads are in flight during this step's MFMAs.
 //   * Planes live in HBM in a K-BLOCKED layout (plane_index() in uvad_internal.h): [row tile][16-column block][row][16], so
-//     the slab a workgroup needs for one 16-deep k-block of one plane is ONE contiguous 4 KiB (A, 128 rows) / 2 KiB (W, 64
-//     rows) run and every DMA wave-instruction reads eight full 128-byte lines.  (Row-major planes were measured first:
-//     a K-step then touches 32-byte pieces of rows 512 bytes apart, 32 L2 requests per wave-instruction, and the kernel is
-//     bound by the L2 request rate -- TA busy 77 %, MFMA busy 21 %, profiles/README.md.)
+//     the slab a workgroup needs for one 16-deep k-block of one plane is ONE contiguous 4 KiB run (128 rows) and every DMA
+//     wave-instruction reads eight full 128-byte lines.  (Row-major planes were measured first: a K-step then touches
+//     32-byte pieces of rows 512 bytes apart, 32 L2 requests per wave-instruction, and the kernel is bound by the L2
+//     request rate -- TA busy 77 %, MFMA busy 21 %, profiles/README.md.)
 //   * The LDS image is dense (a DMA wave-instruction writes 1 KiB contiguously); bank conflicts of the ds_read_b128
 //     fragment reads are removed by an XOR swizzle of the 16-byte chunk index applied to the DMA's per-lane SOURCE
 //     address and to the read address (cdna_hip_programming.md section 5.4 rule 21).
-//   * The epilogue stores straight from the accumulators: the 32x32 C layout gives each store instruction two full 128-byte
-//     row segments (measured in round 1: staging the tile through LDS for 16-byte stores moved no time).
+//   * Epilogue: the tile is assembled in LDS (over the operand stages) and leaves as unmasked 16-byte stores into its
+//     contiguous run of the blocked gate matrix / of the K-blocked output planes (dword stores straight from the 32x32 C
+//     layout reached 2.9 TB/s and did not overlap the K loops of the other workgroups).
 //   * Block ids are remapped so that the N-tiles sharing one A row panel run on the same XCD (private L2) back to back.
 #include "uvad_internal.h"
 
@@ -48,16 +51,32 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-constexpr int BM = PLANE_TILE, BN = 64;
+constexpr int BM = PLANE_TILE, BN = 128, GT = 64;   // GT: column width of a tile of the blocked gate matrix (g_index)
 
-// LDS image of one 16-deep k-block (f16 elements): 128 rows of A hi, 128 of A lo, 64 rows each of W P0 / P1 / P2; a row is
-// 16 elements = two 16-byte chunks, chunk c of row r sits at slot c ^ ((r >> 3) & 1) (rows r and r + 8 share a bank line)
-constexpr int KB_AHI = 0, KB_ALO = BM * 16, KB_W0 = 2 * BM * 16, KB_W1 = KB_W0 + BN * 16, KB_W2 = KB_W1 + BN * 16, KB_ELEMS = KB_W2 + BN * 16;
+// LDS image of one 16-deep k-block (f16 elements): 128 rows each of A hi, A lo, W P0, W P1, W P2; a row is 16 elements = two
+// 16-byte chunks, chunk c of row r sits at slot c ^ ((r >> 3) & 1) (rows r and r + 8 share a bank line)
+constexpr int SLAB = 128 * 16;
+constexpr int KB_AHI = 0, KB_ALO = SLAB, KB_W0 = 2 * SLAB, KB_W1 = 3 * SLAB, KB_W2 = 4 * SLAB, KB_ELEMS = 5 * SLAB;
+static_assert(BM == 128 && BN == 128, "the DMA plan moves five 128-row slabs per k-block, one 32-row piece per wave each");
 
-template <bool OUT_PLANES>
-__global__ __launch_bounds__(256, 4) void gemm_f16p_kernel(GemmArgs a, int mt, int nt) {
-    constexpr int STAGE = KB_ELEMS, NST = 2;   // two LDS stages of one 16-deep k-block each
-    constexpr int LDS_ELEMS = NST * STAGE > BM * BN * 2 ? NST * STAGE : BM * BN * 2;   // the f32 output tile of the blocked epilogue aliases the stages
+#ifndef UVAD_F16P_NST
+#define UVAD_F16P_NST 2
+#endif
+#ifndef UVAD_F16P_OCC
+#define UVAD_F16P_OCC 3
+#endif
+
+template <bool OUT_PLANES, int NSTAGES>
+__global__ __launch_bounds__(256, NSTAGES == 2 ? UVAD_F16P_OCC : 1) void gemm_f16p_kernel(GemmArgs a, int mt, int nt) {
+    // LDS stages of one 16-deep k-block each (20 KiB).  NSTAGES = 2, the throughput instance: a plain double buffer, three
+    // workgroups per CU hide each other's waits (rings of 3 and 4 stages with counted vmcnt waits measured the same or slower,
+    // also for the N = 128 feed-forward layers).  NSTAGES = 4, the latency instance for launches that do not fill the chip
+    // (the per-chunk steps of uvad_stream_step: 64 workgroups at 512 feeds): three k-blocks in flight per workgroup, because
+    // there the K loop is a chain of L2 / HBM round trips with nothing else on the CU to cover them.
+    constexpr int STAGE = KB_ELEMS, NST = NSTAGES;
+    constexpr bool EPI_HALVES = NST * STAGE < BM * BN * 2;   // the f32 output tile of the blocked epilogue aliases the stages: whole, or one 128 x 64 half at a time
+    constexpr int EPI_ELEMS = EPI_HALVES ? BM * GT * 2 : BM * BN * 2;
+    constexpr int LDS_ELEMS = NST * STAGE > EPI_ELEMS ? NST * STAGE : EPI_ELEMS;
     __shared__ __attribute__((aligned(16))) unsigned short lds[LDS_ELEMS];
 
     if (a.gate && (*a.gate != 0) != (a.gate_run_if_set != 0)) return;   // device-side kernel selection (see GemmArgs)
@@ -70,126 +89,207 @@ __global__ __launch_bounds__(256, 4) void gemm_f16p_kernel(GemmArgs a, int mt, i
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- DMA plan.  Per k-block FOUR wave-instructions per wave:
-    //      a quarter of the A hi slab, a quarter of the A lo slab, a quarter of the W P0 slab (waves 0-1) or W P1 slab (waves 2-3),
-    //      and -- lanes 0-31 only -- a quarter of the W P2 slab.  A lane always fetches the chunk that belongs at its LDS slot
-    //      (slot s of row r holds chunk s ^ ((r >> 3) & 1)): bases are wave-uniform, lane offsets are constants.
+    // ---- DMA plan.  Per k-block FIVE wave-instructions per wave: rows [32 wave, 32 wave + 32) of each of the five slabs.  A lane
+    //      always fetches the chunk that belongs at its LDS slot (slot s of row r holds chunk s ^ ((r >> 3) & 1)): bases are
+    //      wave-uniform, the lane offset is one constant.
     const int nkb = a.K / 16;                                   // k-blocks of the whole contraction (K is a multiple of 32)
-    const unsigned short *a_hi = a.Ah + (size_t)m_tile * nkb * (BM * 16);
-    const unsigned short *a_lo = a.Al + (size_t)m_tile * nkb * (BM * 16);
-    const size_t wplane = (size_t)((a.N + BN - 1) / BN) * nkb * (BN * 16);   // elements per W plane (N padded to whole 64-row tiles)
-    const unsigned short *w_a = a.Wsplit16 + (wave < 2 ? 0 : wplane) + (size_t)n_tile * nkb * (BN * 16);   // P0 or P1
-    const unsigned short *w_2 = a.Wsplit16 + 2 * wplane + (size_t)n_tile * nkb * (BN * 16);
-    const int ra = tid >> 1, rw = (tid & 127) >> 1, q2 = wave * 32 + (lane & 31), r2 = q2 >> 1;
-    const unsigned off_a = (unsigned)((ra * 2 + ((tid & 1) ^ ((ra >> 3) & 1))) * 8);
-    const unsigned off_w = (unsigned)((rw * 2 + ((tid & 1) ^ ((rw >> 3) & 1))) * 8);
-    const unsigned off_2 = (unsigned)((r2 * 2 + ((q2 & 1) ^ ((r2 >> 3) & 1))) * 8);
+    const size_t wplane = (size_t)((a.N + BN - 1) / BN) * nkb * SLAB;   // elements per W plane (N padded to whole 128-row tiles)
+    const int ra = tid >> 1;
+    const unsigned off = (unsigned)((ra * 2 + ((tid & 1) ^ ((ra >> 3) & 1))) * 8);
+    const unsigned short *a_hi = a.Ah + (size_t)m_tile * nkb * SLAB + off;
+    const unsigned short *a_lo = a.Al + (size_t)m_tile * nkb * SLAB + off;
+    const unsigned short *w_0 = a.Wsplit16 + (size_t)n_tile * nkb * SLAB + off;
+    const unsigned short *w_1 = w_0 + wplane, *w_2 = w_0 + 2 * wplane;
     auto issue = [&](int stage, int kb) {
-        unsigned short *img = lds + stage * STAGE;
-        const size_t ka = (size_t)kb * (BM * 16), kw = (size_t)kb * (BN * 16);
-        __builtin_amdgcn_global_load_lds((gptr_t)(a_hi + ka + off_a), (lptr_t)(img + KB_AHI + wave * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(a_lo + ka + off_a), (lptr_t)(img + KB_ALO + wave * 512), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(w_a + kw + off_w), (lptr_t)(img + KB_W0 + wave * 512), 16, 0, 0);   // waves 2-3 land in KB_W1
-        if (lane < 32) __builtin_amdgcn_global_load_lds((gptr_t)(w_2 + kw + off_2), (lptr_t)(img + KB_W2 + wave * 256), 16, 0, 0);
+        unsigned short *img = lds + stage * STAGE + wave * 512;
+        const size_t k = (size_t)kb * SLAB;
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_hi + k), (lptr_t)(img + KB_AHI), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_lo + k), (lptr_t)(img + KB_ALO), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_0 + k), (lptr_t)(img + KB_W0), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_1 + k), (lptr_t)(img + KB_W1), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_2 + k), (lptr_t)(img + KB_W2), 16, 0, 0);
     };
 
-    f32x16 hi0, hi1, lo0, lo1;
+    // accumulators of the wave's 64 x 64 tile: [row block][column block], hi and lo sets
+    f32x16 hi[2][2], lo[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { hi0[r] = 0.f; hi1[r] = 0.f; lo0[r] = 0.f; lo1[r] = 0.f; }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { hi[i][j][r] = 0.f; lo[i][j][r] = 0.f; }
 
-    // fragment addresses (f16 elements inside a k-block image): lane = (row fr of the 32-row MFMA tile, k-half fh)
+    // fragment addresses (f16 elements inside a slab): lane = (row fr of the 32-row MFMA tile, k-half fh)
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 31, fh = lane >> 5;
-    const int arow0 = wr * 64 + fr, arow1 = arow0 + 32, wrow = wc * 32 + fr;
-    const int fa0 = arow0 * 16 + ((fh ^ ((arow0 >> 3) & 1)) * 8), fa1 = arow1 * 16 + ((fh ^ ((arow1 >> 3) & 1)) * 8);
-    const int fw = wrow * 16 + ((fh ^ ((wrow >> 3) & 1)) * 8);
+    int fa[2], fw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ar = wr * 64 + i * 32 + fr, wrw = wc * 64 + i * 32 + fr;
+        fa[i] = ar * 16 + ((fh ^ ((ar >> 3) & 1)) * 8);
+        fw[i] = wrw * 16 + ((fh ^ ((wrw >> 3) & 1)) * 8);
+    }
 
-    // ---- k loop: plain double buffer, one barrier per k-block; the DMA of k-block kt + 1 is in flight during the MFMAs of kt.
-    //      (A 3- and a 4-stage ring with counted vmcnt waits and raw barriers measured the same 2.27 ms for the four projections:
-    //      with five workgroups per CU the k loop runs the f16 matrix pipe at ~65 %, it is not waiting for the DMA.)
-    issue(0, 0);
+    // ---- k loop: one barrier per k-block; the DMA of the next k-block(s) is in flight during the MFMAs of this one.
+    //      Per wave and k-block: 10 ds_read_b128 and 16 MFMAs (4 products x 2 x 2 tiles); per workgroup 20 KiB through the
+    //      vector memory path for 64 MFMAs (the 128 x 64 tile of the first version moved 14 KiB per 32 MFMAs and was bound by
+    //      exactly that: TA busy 77-86 %, matrix pipe 65 % inside the k loop).
+#ifndef UVAD_F16P_ABL_NODMA
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+        if (p < nkb) issue(p, p);
+#endif
     for (int kt = 0; kt < nkb; ++kt) {
-        __syncthreads();   // (hipcc waits vmcnt(0) here) k-block kt has landed for every wave; everyone is done reading k-block kt-1
+        if constexpr (NST == 2) {
+            __syncthreads();   // (hipcc waits vmcnt(0) here) k-block kt has landed for every wave; everyone is done reading k-block kt-1
+        } else {
+            // k-blocks kt .. kt+NST-2 are in flight (5 loads each, fewer at the tail): wait for the oldest only
+            if (kt + NST - 2 < nkb) __builtin_amdgcn_s_waitcnt(0x0f70 | (5 * (NST - 2) & 0xf) | (((5 * (NST - 2)) >> 4) << 14));
+            else __builtin_amdgcn_s_waitcnt(0x0f70);
+            __builtin_amdgcn_s_barrier();
+        }
 #ifndef UVAD_F16P_ABL_NODMA   // diagnostic builds (tools/stage_times.py --lib): outputs of ablated builds are meaningless
-        if (kt + 1 < nkb) issue((kt + 1) % NST, kt + 1);
+        if (kt + NST - 1 < nkb) issue((kt + NST - 1) % NST, kt + NST - 1);
 #endif
         const unsigned short *st = lds + (kt % NST) * STAGE;
-        const f16x8 a0h = *reinterpret_cast<const f16x8 *>(st + KB_AHI + fa0);
-        const f16x8 a0l = *reinterpret_cast<const f16x8 *>(st + KB_ALO + fa0);
-        const f16x8 a1h = *reinterpret_cast<const f16x8 *>(st + KB_AHI + fa1);
-        const f16x8 a1l = *reinterpret_cast<const f16x8 *>(st + KB_ALO + fa1);
-        const f16x8 w0 = *reinterpret_cast<const f16x8 *>(st + KB_W0 + fw);
-        const f16x8 w1 = *reinterpret_cast<const f16x8 *>(st + KB_W1 + fw);
-        const f16x8 w2 = *reinterpret_cast<const f16x8 *>(st + KB_W2 + fw);
+        f16x8 ah[2], al[2], w0[2], w1[2], w2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8 *>(st + KB_AHI + fa[i]);
+            w0[i] = *reinterpret_cast<const f16x8 *>(st + KB_W0 + fw[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            w1[i] = *reinterpret_cast<const f16x8 *>(st + KB_W1 + fw[i]);
+            al[i] = *reinterpret_cast<const f16x8 *>(st + KB_ALO + fa[i]);
+            w2[i] = *reinterpret_cast<const f16x8 *>(st + KB_W2 + fw[i]);
+        }
 #ifdef UVAD_F16P_ABL_NOMFMA
-        asm volatile("" ::"v"(a0h), "v"(a0l), "v"(a1h), "v"(a1l), "v"(w0), "v"(w1), "v"(w2));
+        asm volatile("" ::"v"(ah[0]), "v"(al[0]), "v"(ah[1]), "v"(al[1]), "v"(w0[0]), "v"(w1[0]), "v"(w2[0]), "v"(w0[1]), "v"(w1[1]), "v"(w2[1]));
         continue;
 #endif
-        lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w1, lo0, 0, 0, 0);
-        lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w1, lo1, 0, 0, 0);
-        lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, w0, lo0, 0, 0, 0);
-        lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, w0, lo1, 0, 0, 0);
-        lo0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w2, lo0, 0, 0, 0);
-        lo1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w2, lo1, 0, 0, 0);
-        hi0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, w0, hi0, 0, 0, 0);
-        hi1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, w0, hi1, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) hi[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], w0[j], hi[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], w1[j], lo[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], w0[j], lo[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) lo[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], w2[j], lo[i][j], 0, 0, 0);
     }
 
     // ---- epilogue: (hi + lo * 2^-11) * 2^-S + bias, activation.  C layout of the 32x32 MFMA: register r of lane (fr, fh) =
     //      row 8*(r>>2) + 4*fh + (r&3), column fr.
-    const int col = C0 + wc * 32 + fr;
-    const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;
     if (!OUT_PLANES && a.c_blocked) {
-        // Tile-blocked gate matrix: this workgroup's 128 x 64 tile is ONE contiguous 32 KiB run of G (whole tiles exist for
-        // the padding rows too), so the tile goes through LDS and leaves as unmasked 16-byte stores, 1 KiB per wave-instruction
-        // (dword stores straight from the accumulators measured 2.9 TB/s and did not overlap with the K loops).
+        // Tile-blocked gate matrix: this workgroup's 128 x 128 tile is two adjacent 128 x 64 tiles of G = ONE contiguous 64 KiB
+        // run (whole tiles exist for the padding rows too), so the tile goes through LDS and leaves as unmasked 16-byte
+        // stores, 1 KiB per wave-instruction (dword stores straight from the accumulators measured 2.9 TB/s and did not
+        // overlap with the K loops).
         float *Ct = reinterpret_cast<float *>(lds);
-        __syncthreads();   // every wave is done reading the last stage
+        float *dst = a.C + ((size_t)m_tile * (a.N / GT) + (size_t)n_tile * (BN / GT)) * (BM * GT);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const f32x16 &HI = mi ? hi1 : hi0;
-            const f32x16 &LO = mi ? lo1 : lo0;
+        for (int half = 0; half < (EPI_HALVES ? 2 : 1); ++half) {
+            __syncthreads();   // every wave is done reading the last stage / storing the previous half
+            if (!EPI_HALVES || wc == half) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lr = wr * 64 + mi * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
-                Ct[lr * BN + wc * 32 + fr] = __builtin_fmaf(__builtin_fmaf(LO[r], 0.00048828125f, HI[r]), a.wscale, bias);
+                for (int j = 0; j < 2; ++j) {
+                    const int lc = wc * 64 + j * 32 + fr;                    // column inside the 128-wide tile
+                    const float bias = a.bias ? a.bias[C0 + lc] : 0.f;
+                    float *Cj = Ct + (EPI_HALVES ? 0 : (lc / GT) * (BM * GT)) + (lc % GT);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int lr = wr * 64 + i * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+                            Cj[lr * GT] = __builtin_fmaf(__builtin_fmaf(lo[i][j][r], 0.00048828125f, hi[i][j][r]), a.wscale, bias);
+                        }
+                }
             }
-        }
-        __syncthreads();
-        float *dst = a.C + ((size_t)m_tile * (a.N / BN) + n_tile) * (BM * BN);
+            __syncthreads();
+            constexpr int N4 = (EPI_HALVES ? BM * GT : BM * BN) / 4;
 #pragma unroll
-        for (int j = 0; j < BM * BN / 4 / 256; ++j) {
-            const int q = tid + 256 * j;
+            for (int j = 0; j < N4 / 256; ++j) {
+                const int q = tid + 256 * j;
 #ifdef UVAD_F16P_ABL_NOSTORE
-            if (Ct[q * 4] == 12345.678f)
+                if (Ct[q * 4] == 12345.678f)
 #endif
-            *reinterpret_cast<float4 *>(dst + (size_t)q * 4) = *reinterpret_cast<const float4 *>(Ct + q * 4);
+                *reinterpret_cast<float4 *>(dst + (size_t)half * (BM * GT) + (size_t)q * 4) = *reinterpret_cast<const float4 *>(Ct + q * 4);
+            }
         }
         return;
     }
+    if constexpr (OUT_PLANES) {
+        if (a.ldc % BN == 0) {
+            // Whole 128-column tiles of K-blocked planes: the tile's image of ONE plane -- 8 column blocks x 128 rows x 16 -- is a
+            // contiguous 32 KiB run (plane_index), rows of the padding tile included; it is assembled in LDS, one plane after the
+            // other, and leaves as 16-byte stores (2-byte stores straight from the accumulators: 0.19 ms for the 65 MB of a
+            // 256 -> 128 layer at cfg 2).
+            unsigned short *Pt = lds;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const f32x16 &HI = mi ? hi1 : hi0;
-        const f32x16 &LO = mi ? lo1 : lo0;
+            for (int pl = 0; pl < 2; ++pl) {
+                __syncthreads();   // every wave is done reading the last stage / storing the other plane
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = R0 + wr * 64 + mi * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
-            float v = __builtin_fmaf(__builtin_fmaf(LO[r], 0.00048828125f, HI[r]), a.wscale, bias);
-            if (a.act == 1) v = v >= 0.f ? v : a.leaky_slope * v;
-            if constexpr (OUT_PLANES) {
-                // consumer = another f16p GEMM whose K is ldc (N rounded up to 32): its padding columns must read as zero
-                if (row < a.M && col < a.ldc) {
-                    if (col >= a.N) v = 0.f;
-                    const _Float16 h = (_Float16)v;
-                    const _Float16 l = (_Float16)((v - (float)h) * 2048.0f);
-                    const size_t o = plane_index(row, col, a.ldc);
-                    a.Ch[o] = __builtin_bit_cast(unsigned short, h);
-                    a.Cl[o] = __builtin_bit_cast(unsigned short, l);
+                for (int j = 0; j < 2; ++j) {
+                    const int lc = wc * 64 + j * 32 + fr, col = C0 + lc;
+                    const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;
+                    unsigned short *Pj = Pt + (lc >> 4) * (BM * 16) + (lc & 15);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int lr = wr * 64 + i * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+                            float v = __builtin_fmaf(__builtin_fmaf(lo[i][j][r], 0.00048828125f, hi[i][j][r]), a.wscale, bias);
+                            if (a.act == 1) v = v >= 0.f ? v : a.leaky_slope * v;
+                            if (col >= a.N) v = 0.f;   // padding columns of the consumer's K must read as zero
+                            const _Float16 h = (_Float16)v;
+                            const _Float16 piece = pl == 0 ? h : (_Float16)((v - (float)h) * 2048.0f);
+                            Pj[lr * 16] = __builtin_bit_cast(unsigned short, piece);
+                        }
                 }
-            } else {
-                if (row < a.M && col < a.N) a.C[(size_t)row * a.ldc + col] = v;
+                __syncthreads();
+                unsigned short *dstp = (pl == 0 ? a.Ch : a.Cl) + ((size_t)m_tile * (a.ldc / 16) + (size_t)n_tile * (BN / 16)) * (BM * 16);
+#pragma unroll
+                for (int k = 0; k < BM * BN / 8 / 256; ++k) {
+                    const int q = tid + 256 * k;
+                    *reinterpret_cast<uint4 *>(dstp + (size_t)q * 8) = *reinterpret_cast<const uint4 *>(Pt + q * 8);
+                }
             }
+            return;
         }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = C0 + wc * 64 + j * 32 + fr;
+        const float bias = (a.bias && col < a.N) ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = R0 + wr * 64 + i * 32 + 8 * (r >> 2) + 4 * fh + (r & 3);
+                float v = __builtin_fmaf(__builtin_fmaf(lo[i][j][r], 0.00048828125f, hi[i][j][r]), a.wscale, bias);
+                if (a.act == 1) v = v >= 0.f ? v : a.leaky_slope * v;
+                if constexpr (OUT_PLANES) {
+                    // consumer = another f16p GEMM whose K is ldc (N rounded up to 32): its padding columns must read as zero
+                    if (row < a.M && col < a.ldc) {
+                        if (col >= a.N) v = 0.f;
+                        const _Float16 h = (_Float16)v;
+                        const _Float16 l = (_Float16)((v - (float)h) * 2048.0f);
+                        const size_t o = plane_index(row, col, a.ldc);
+                        a.Ch[o] = __builtin_bit_cast(unsigned short, h);
+                        a.Cl[o] = __builtin_bit_cast(unsigned short, l);
+                    }
+                } else {
+                    if (row < a.M && col < a.N) a.C[(size_t)row * a.ldc + col] = v;
+                }
+            }
     }
 }
 
@@ -232,7 +332,7 @@ __global__ __launch_bounds__(256) void split_features_kernel(const float *x, int
 int gemm_f16p_padded_k(int K) { return (K + 31) / 32 * 32; }
 
 // host: f32 [N][ldw] (rows zero-padded to ldw, a multiple of 32) -> three f16 planes of w * 2^S that add up to it EXACTLY (see the
-// header), each in the K-blocked layout with 64-row tiles (N padded to whole tiles with zero rows): out holds
+// header), each in the K-blocked layout with 128-row tiles (N padded to whole tiles with zero rows): out holds
 // 3 * weight_plane_elems(N, ldw) elements; *wscale = 2^-S.  false: a weight is non-finite (the matrix cannot be represented).
 size_t weight_plane_elems(int N, int ldw) { return (size_t)((N + BN - 1) / BN) * BN * ldw; }
 
@@ -277,13 +377,14 @@ hipError_t launch_gemm_f16p(const GemmArgs &a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return hipSuccess;
     if (!a.Ah || !a.Al || !a.Wsplit16 || a.K <= 0 || (a.K & 31) || a.ldw != a.K) return hipErrorInvalidValue;
     if (a.out_planes ? (!a.Ch || !a.Cl) : !a.C) return hipErrorInvalidValue;
-    if (a.c_blocked && (a.out_planes || a.act != 0 || a.N % BN != 0)) return hipErrorInvalidValue;   // the gate matrix: whole 64-column tiles, no activation
+    if (a.c_blocked && (a.out_planes || a.act != 0 || a.N % BN != 0)) return hipErrorInvalidValue;   // the gate matrix: whole 128-column tiles, no activation
     const int mt = (a.M + BM - 1) / BM, nt = ((a.out_planes ? a.ldc : a.N) + BN - 1) / BN;
     const int grid = ((mt + 7) / 8) * 8 * nt;
-    if (a.out_planes)
-        hipLaunchKernelGGL((gemm_f16p_kernel<true>), dim3(grid), dim3(256), 0, s, a, mt, nt);
-    else
-        hipLaunchKernelGGL((gemm_f16p_kernel<false>), dim3(grid), dim3(256), 0, s, a, mt, nt);
+    const bool small = (long)mt * nt <= 512;   // fewer than two workgroups per CU of an MI355X: latency instance
+    if (a.out_planes && small) hipLaunchKernelGGL((gemm_f16p_kernel<true, 4>), dim3(grid), dim3(256), 0, s, a, mt, nt);
+    else if (a.out_planes) hipLaunchKernelGGL((gemm_f16p_kernel<true, UVAD_F16P_NST>), dim3(grid), dim3(256), 0, s, a, mt, nt);
+    else if (small) hipLaunchKernelGGL((gemm_f16p_kernel<false, 4>), dim3(grid), dim3(256), 0, s, a, mt, nt);
+    else hipLaunchKernelGGL((gemm_f16p_kernel<false, UVAD_F16P_NST>), dim3(grid), dim3(256), 0, s, a, mt, nt);
     return hipGetLastError();
 }
 

@@ -22,7 +22,7 @@ __host__ __device__ inline size_t plane_index(size_t row, int col, int width) {
 inline size_t plane_rows(size_t M) { return (M + PLANE_TILE - 1) / PLANE_TILE * PLANE_TILE; }
 
 // The gate pre-activations G (output of the projection GEMMs, input of the recurrent kernels) are TILE-BLOCKED:
-// [128-row tile][64-column tile][128][64] f32, so a GEMM workgroup's 128 x 64 output tile is one contiguous 32 KiB run
+// [128-row tile][64-column tile][128][64] f32, so a GEMM workgroup's 128 x 128 output tile (two adjacent tiles) is one contiguous 64 KiB run
 // (row-major G made every workgroup write 128 pieces of 256 bytes 4 KiB apart: measured 2.6 TB/s, not overlapped with
 // the K loops) and the 4 rows x 64 gate columns (16 units x 4 gates) a recurrent wave reads per step are one contiguous KiB.
 // ncols (= 4 * hidden * directions) is a multiple of 64; a G of M rows occupies plane_rows(M) * ncols floats.
@@ -42,7 +42,7 @@ struct GemmArgs {
                          // each row zero-padded to ldw = gemm_padded_k(K) floats
     // ---- gemm_f16p.hip operands
     const unsigned short *Ah, *Al;    // K-blocked f16 planes of the activations, K columns (columns past the true width zero)
-    const unsigned short *Wsplit16;   // w * 2^S as three K-blocked f16 planes (64-row tiles) that add up to it exactly
+    const unsigned short *Wsplit16;   // w * 2^S as three K-blocked f16 planes (128-row tiles) that add up to it exactly
     float wscale;                     // 2^-S
     unsigned short *Ch, *Cl;          // out_planes: K-blocked f16 planes of the result, ldc columns ([N, ldc) written as zero)
     int out_planes;
