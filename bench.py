@@ -200,7 +200,7 @@ def main():
         else:
             kern, flops_launch, dur_ms, peak = rec_kernel, frames_step * rec_f / L, ms["recurrent"] / L, PEAK_F32_MFMA_TFLOPS
     else:
-        kern, flops_launch, dur_ms, peak = "gemm_f16p_kernel<false>", 4.0 * frames_step * proj_f / L, ms["proj"] / L, PEAK_F16_MFMA_TFLOPS
+        kern, flops_launch, dur_ms, peak = "gemm_f16p_kernel<false, 2>", 4.0 * frames_step * proj_f / L, ms["proj"] / L, PEAK_F16_MFMA_TFLOPS
     achieved = flops_launch / (dur_ms * 1e-3) / 1e12
     # HBM bytes per launch of that kernel from the rocprofv3 PMC passes of this same workload (FETCH_SIZE doubled
     # per MI355X_MICROARCH.md + WRITE_SIZE); bench.py cannot collect PMC counters itself, so the committed
@@ -295,7 +295,7 @@ def sequential_latency(rt, dev, pcm, steps, world, forced=0):
     return {"value": frames / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps_in_flight": 1, "recurrent_tile": used,
             "roofline": {"kernel": "lstm_rec_kernel<128, 8, true>", "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": launch_ms},
-            "projection_roofline": {"kernel": "gemm_f16p_kernel<false>", "bound": "mfma", "achieved": ptf, "peak": PEAK_F16_MFMA_TFLOPS,
+            "projection_roofline": {"kernel": "gemm_f16p_kernel<false, 2>", "bound": "mfma", "achieved": ptf, "peak": PEAK_F16_MFMA_TFLOPS,
                                     "unit": "TFLOP/s", "frac": ptf / PEAK_F16_MFMA_TFLOPS, "avg_launch_ms": proj_ms,
                                     "note": "f16-pipe rate (4 MFMA products per f32-equivalent product), the launch alone on the GPU; average of the "
                                             "K = 64 and the three K = 256 projections"},

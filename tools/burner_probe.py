@@ -26,6 +26,10 @@ victims = {
     "torch.sin": lambda: torch.sin(x),
     "torch.fft.rfft": lambda: torch.view_as_real(torch.fft.rfft(x.view(-1, 512))),
 }
+mw = uvad_amd.PyanNet(); mw.build(); seed_weights(mw, 1234, 4.0); mw = mw.to(dev).eval()
+rtw = mw.runtime(dev)
+wav = synth_pcm_device(256, 80000, seed=7, device=dev)
+victims["sincnet"] = lambda: rtw.sincnet(wav)
 A16 = torch.randn(8192, 8192, device=dev, dtype=torch.float16)
 B16 = torch.randn(8192, 8192, device=dev, dtype=torch.float16)
 def aggressor(kind):

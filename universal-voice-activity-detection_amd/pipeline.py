@@ -3,7 +3,7 @@
 Why: the recurrence of one batch is a serial chain of 4 x T steps that cannot use the chip -- at B = 256 its latency form
 occupies 128 of the 256 CUs for 5.3 ms, its throughput form (recurrent_tile=16) 32 CUs for 7.4 ms.  Independent batches
 submitted on other HIP streams run their feature kernels, projections and recurrences on the CUs one batch leaves idle
-(bench.py at BASELINE cfg 2: 32 M frames/s one step at a time, 63 M with twelve in flight and the throughput form).  Each slot is
+(bench.py at BASELINE cfg 2: 32 M frames/s one step at a time, 68 M with twelve in flight and the throughput form).  Each slot is
 a full VadRuntime (own weights copy and workspace) bound to its own stream; results are identical to the sequential path with
 the same recurrent form (same kernels, same launch shapes).
 
