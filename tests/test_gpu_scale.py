@@ -217,3 +217,22 @@ def test_bench_regime_outputs_identical_to_single_calls():
     d = json.loads(line[-1])
     print(d)
     assert out.returncode == 0 and d["steps_with_wrong_logits"] == 0, d
+
+
+
+def test_feature_kernel_beside_a_synthetic_mfma_neighbour():
+    """tools/burner_probe.py: the feature kernel and the classifier on one stream while a small kernel that loops over MFMAs, an LDS
+    read and s_barrier (tools/mfma_burner.hip, built by __graft_entry__.build()) runs on another.  With 64-bit LDS operations in its
+    scratch the feature kernel returned wrong frames in every overlapping call (and so does stock rocFFT); with 32-bit operations
+    only it must be bit-identical to its own result obtained alone."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "tools", "libburner.so")):
+        pytest.skip("tools/libburner.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "burner_probe.py"), "fbank", "classify"],
+                         capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("SUMMARY")]
+    assert line, (out.stdout[-1000:], out.stderr[-2000:])
+    d = json.loads(line[-1].split(" ", 1)[1])
+    print(out.stdout[-600:])
+    assert d == {"fbank": 0, "classify": 0}, d

@@ -36,6 +36,7 @@ def aggressor(kind):
     if kind == "burner": lib.burner_launch(0, sink.data_ptr(), 8192, 400, sb.cuda_stream)
     elif kind == "matmul": torch.matmul(A16, B16)       # the stock f16 GEMM of the installed BLAS (MFMA + LDS + barriers)
 only = [a for a in sys.argv[1:] if not a.endswith('.so')]
+total_bad = {}
 for vname, fn in victims.items():
     if only and vname not in only: continue
     ref = fn().clone()
@@ -50,3 +51,5 @@ for vname, fn in victims.items():
             torch.cuda.synchronize(dev)
             bad += sum(int(not torch.equal(o, ref)) for o in outs)
         print(f"victim {vname} beside '{kind}': {bad} wrong of 90")
+        total_bad[vname] = total_bad.get(vname, 0) + bad
+print("SUMMARY", __import__("json").dumps(total_bad))
