@@ -67,7 +67,7 @@ static_assert(BM == 128 && BN == 128, "the DMA plan moves five 128-row slabs per
 #endif
 
 template <bool OUT_PLANES, int NSTAGES>
-__global__ __launch_bounds__(256, NSTAGES == 2 ? UVAD_F16P_OCC : 1) void gemm_f16p_kernel(GemmArgs a, int mt, int nt) {
+__global__ __launch_bounds__(256, NSTAGES == 2 ? (OUT_PLANES ? 2 : UVAD_F16P_OCC) : 1) void gemm_f16p_kernel(GemmArgs a, int mt, int nt) {
     // LDS stages of one 16-deep k-block each (20 KiB).  NSTAGES = 2, the throughput instance: a plain double buffer, three
     // workgroups per CU hide each other's waits (rings of 3 and 4 stages with counted vmcnt waits measured the same or slower,
     // also for the N = 128 feed-forward layers).  NSTAGES = 4, the latency instance for launches that do not fill the chip
