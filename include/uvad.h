@@ -41,7 +41,7 @@ extern "C" {
 #define UVAD_E_WORKSPACE   -4
 #define UVAD_E_UNSUPPORTED -5
 
-#define UVAD_ABI_VERSION 2
+#define UVAD_ABI_VERSION 3
 
 typedef struct uvad_ctx uvad_ctx; /* opaque */
 
@@ -141,14 +141,20 @@ int uvad_get_taps(uvad_ctx *, int B, int T, float *d_lstm_out, float *d_lin_out,
  * device memory of uvad_stream_state_bytes(ctx, B) bytes holding the PCM tail and (h, c) of every layer;
  * uvad_stream_reset (re)starts all B streams.  The right-edge reflection of the offline path needs the end
  * of the signal and is therefore never produced (streams are open-ended).
- * uvad_stream_step is asynchronous but NOT replay-safe under hipGraph capture: the number of complete frames, the
- * PCM-tail ping-pong parity and the first-chunk reflection are host-side counters baked into the launch arguments
- * at enqueue time, so a captured step replayed twice would repeat one step.  Enqueue it per chunk. */
+ * uvad_stream_step is asynchronous but NOT replay-safe by itself under hipGraph capture: the number of complete frames, the
+ * PCM-tail ping-pong parity and the first-chunk reflection are host-side counters baked into the launch arguments at
+ * enqueue time.  Replay is offered explicitly: uvad_stream_peek says what the NEXT step will bake in -- two steps with the
+ * same (B, chunk, k, offset, parity, first) and the same buffers enqueue identical work, so a graph captured around one
+ * uvad_stream_step can be replayed for the other, followed by uvad_stream_advance, which moves the counters exactly as the
+ * step would have and returns its k (VadRuntime.stream_step does this; at the reference geometry a stream group settles
+ * into two graphs, one per parity). */
 size_t uvad_stream_state_bytes(const uvad_ctx *, int B);
 size_t uvad_stream_workspace_bytes(const uvad_ctx *, int B, int chunk);
 int uvad_stream_reset(uvad_ctx *, void *d_state, int B, void *stream);
 int uvad_stream_step(uvad_ctx *, const float *d_pcm_chunk, int B, int chunk, void *d_state,
                      float *d_logits, int ld_logits, void *d_workspace, size_t ws_bytes, void *stream);
+int uvad_stream_peek(const uvad_ctx *, const void *d_state, int chunk, int *k, int64_t *offset, int *parity, int *first);
+int uvad_stream_advance(uvad_ctx *, void *d_state, int chunk);
 
 /* Replaces: median_filter (src/utils/helper.py:66-97) as used by VadModel.predict_step
  * (vad_engine.py:204-211): threshold 0.5 then odd `kernel`-tap median, zero padded edges.

@@ -352,6 +352,32 @@ def test_streaming_equals_offline_causal_model(chunk):
     assert np.abs(lg2.cpu().numpy() - want).max() < LOGIT_TOL
 
 
+@pytest.mark.parametrize("chunk", [320, 250, 1600])
+def test_streaming_graph_replay_equals_kernel_by_kernel_enqueue(chunk):
+    """stream_step replays a hipGraph per distinct (k, offset, parity, first) of uvad_stream_peek and moves the counters with
+    uvad_stream_advance: bit-identical to enqueuing every step kernel by kernel (graphs=False), for a chunk that is a multiple
+    of the shift (two graphs after the first step) and one that is not (250 samples: the step shapes cycle)."""
+    import uvad_amd
+    from uvad_amd.synth import synth_pcm, seed_weights
+    dev = torch.device("cuda:0")
+    B, S, F = 5, 16000, 64
+    x = torch.from_numpy(synth_pcm(B, S, seed=78)).to(dev)
+    m = uvad_amd.PyanNet2(lstm={"bidirectional": False}, encoding_dim=F)
+    m.build()
+    seed_weights(m, 1234, 4.0)
+    m.attach_fbank(uvad_amd.FbankConfig(num_filters=F, window_type="povey"))
+    rt = m.to(dev).eval().runtime(dev)
+    runs = {}
+    for graphs in (False, True):
+        st = rt.stream_open(B, chunk, graphs=graphs)
+        outs = [rt.stream_step(st, x[:, i * chunk:(i + 1) * chunk].contiguous()).clone() for i in range(S // chunk)]
+        runs[graphs] = torch.cat(outs, dim=1)
+        if graphs:
+            print(f"chunk {chunk}: {len(st['graphs'])} graphs for {S // chunk} steps")
+            assert len(st["graphs"]) < S // chunk
+    assert runs[True].shape == runs[False].shape and torch.equal(runs[True], runs[False])
+
+
 def test_streaming_rejects_bidirectional_and_unreset_state():
     import uvad_amd
     from uvad_amd import _lib

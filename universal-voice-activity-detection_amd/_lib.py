@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libuvad.so")
 
 UVAD_OK = 0
 ERR_NAMES = {-1: "UVAD_E_ARG", -2: "UVAD_E_HIP", -3: "UVAD_E_STATE", -4: "UVAD_E_WORKSPACE", -5: "UVAD_E_UNSUPPORTED"}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class FbankCfg(C.Structure):
@@ -65,6 +65,9 @@ SIGNATURES = {
     "uvad_stream_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "uvad_stream_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+    "uvad_stream_peek": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int)]),
+    "uvad_stream_advance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "uvad_median_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "uvad_label_runs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "uvad_der_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

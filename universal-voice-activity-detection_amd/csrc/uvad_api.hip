@@ -769,6 +769,23 @@ StreamLayout stream_layout(const uvad_ctx *c, int B) {
     return L;
 }
 int stream_max_frames(const uvad_ctx *c, int chunk) { return chunk / c->fb.frame_shift + 1; }
+// What the next step of a stream group does, from its host-side counters: which tail buffer it reads, whether it is the first
+// chunk (left reflection), how many frames it completes and where the first of them starts inside a staging row.
+struct StreamPlan { int parity = 0, first = 0, k = 0; int64_t offset = 0, n_after = 0; };
+StreamPlan stream_plan(const uvad_ctx *c, const StreamCounters &sc, int chunk) {
+    const int L = c->fb.frame_len, sh = c->fb.frame_shift, n_left = (L - sh) / 2;
+    StreamPlan p;
+    p.parity = (int)(sc.n_steps & 1);
+    p.first = sc.n_samples == 0 ? 1 : 0;
+    const int64_t n_prev = sc.n_samples, n = n_prev + chunk;
+    // frame t spans [t*sh - n_left, t*sh - n_left + L): complete once n >= t*sh - n_left + L
+    const int64_t f_hi = n + n_left - L >= 0 ? (n + n_left - L) / sh : -1;
+    p.k = (int)(f_hi - (sc.n_frames - 1));
+    if (p.k < 0) p.k = 0;
+    p.n_after = n;
+    p.offset = p.k > 0 ? sc.n_frames * sh - n_left - (n_prev - L) : 0;   // offset of the first new frame inside a staging row (tail = L samples)
+    return p;
+}
 }  // namespace
 }  // extern "C++"
 
@@ -814,20 +831,17 @@ int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, vo
     char *wsb = reinterpret_cast<char *>(ws);
     float *staging = reinterpret_cast<float *>(wsb);
     const size_t staging_bytes = align_up((size_t)B * (L + chunk) * sizeof(float));
-    const int par = (int)(sc.n_steps & 1);
-    HIPCHK(c, launch_stream_stage(d_pcm_chunk, B, chunk, S.tail, n_left, sc.n_samples == 0 ? 1 : 0,
+    const StreamPlan plan = stream_plan(c, sc, chunk);
+    const int par = plan.parity;
+    HIPCHK(c, launch_stream_stage(d_pcm_chunk, B, chunk, S.tail, n_left, plan.first,
                                   reinterpret_cast<const float *>(st + S.off_tail[par]),
                                   reinterpret_cast<float *>(st + S.off_tail[par ^ 1]), staging, s));
-    const int64_t n_prev = sc.n_samples, n = n_prev + chunk;
-    // frame t spans [t*sh - n_left, t*sh - n_left + L): complete once n >= t*sh - n_left + L
-    const int64_t f_hi = n + n_left - L >= 0 ? (n + n_left - L) / sh : -1;
-    const int k = (int)(f_hi - (sc.n_frames - 1));
-    sc.n_samples = n;
+    const int k = plan.k;
+    sc.n_samples = plan.n_after;
     sc.n_steps += 1;
     if (k <= 0) return 0;
     if (k > ld_logits) return fail(c, UVAD_E_ARG, "ld_logits smaller than the number of new frames");
-    const int64_t t0 = sc.n_frames;
-    const int64_t o = t0 * sh - n_left - (n_prev - S.tail);   // offset of frame t0 inside a staging row (>= 0)
+    const int64_t o = plan.offset;   // >= 0
     sc.n_frames += k;
     void *cws = wsb + staging_bytes;
     const WsLayout w = carve(c, B, k);
@@ -849,6 +863,27 @@ int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, vo
     const int r = classify_impl(c, feats, B, k, d_logits, nullptr, cws, ws_bytes - staging_bytes, s, false, false, &ss, ld_logits);
     c->timing = timing;
     return r < 0 ? r : k;
+}
+
+int uvad_stream_peek(const uvad_ctx *c, const void *d_state, int chunk, int *k, int64_t *offset, int *parity, int *first) {
+    if (!c || !d_state || chunk <= 0 || !k || !offset || !parity || !first) return UVAD_E_ARG;
+    auto it = c->streams.find(const_cast<void *>(d_state));
+    if (it == c->streams.end() || !c->has_fb) return UVAD_E_STATE;
+    const StreamPlan p = stream_plan(c, it->second, chunk);
+    *k = p.k; *offset = p.offset; *parity = p.parity; *first = p.first;
+    return UVAD_OK;
+}
+
+int uvad_stream_advance(uvad_ctx *c, void *d_state, int chunk) {
+    if (!c || !d_state || chunk <= 0) return UVAD_E_ARG;
+    auto it = c->streams.find(d_state);
+    if (it == c->streams.end() || !c->has_fb) return fail(c, UVAD_E_STATE, "uvad_stream_advance: call uvad_stream_reset on this state first");
+    StreamCounters &sc = it->second;
+    const StreamPlan p = stream_plan(c, sc, chunk);
+    sc.n_samples = p.n_after;
+    sc.n_steps += 1;
+    sc.n_frames += p.k;
+    return p.k;
 }
 
 int uvad_median_filter(uvad_ctx *c, const float *d_probs, int B, int T, int kernel, uint8_t *d_labels, void *stream) {
