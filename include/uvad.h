@@ -41,7 +41,7 @@ extern "C" {
 #define UVAD_E_WORKSPACE   -4
 #define UVAD_E_UNSUPPORTED -5
 
-#define UVAD_ABI_VERSION 3
+#define UVAD_ABI_VERSION 4
 
 typedef struct uvad_ctx uvad_ctx; /* opaque */
 
@@ -93,7 +93,8 @@ int uvad_set_weight(uvad_ctx *, const char *torch_key, const float *host, const 
 
 /* Checks that every tensor is present, repacks into kernel layouts and uploads.  May be called again after
  * further uvad_set_weight calls (weight hot-swap): it waits for the device to go idle, frees the previous
- * upload and replaces it. */
+ * upload and replaces it -- so every hipGraph captured from this context earlier (it bakes the old device pointers of the
+ * weights into its kernel nodes) is INVALID afterwards and must be captured again. */
 int uvad_finalize(uvad_ctx *);
 
 /* T for S samples (lhotse framing; data/test_data.py:23 pins T = S/160 for 5 s cuts). */
@@ -256,6 +257,10 @@ int uvad_streams_overlap(uvad_ctx *, void *stream_a, void *stream_b);
  * Synchronises on the recorded events. */
 int uvad_set_timing(uvad_ctx *, int enabled);
 int uvad_get_timing(uvad_ctx *, float ms[5]);
+/* The same timed call layer by layer: ms[2k] = input projection of LSTM layer k (x * W_ih^T, nn.LSTM inside PyanNet2.forward,
+ * PyanNet2.py:169-172), ms[2k+1] = its recurrence; n = capacity of ms in floats (>= 2 * num_layers).  Returns the number of
+ * floats written.  bench.py reads the K = 256 projection and one recurrent launch from here for its roofline object. */
+int uvad_get_layer_timing(uvad_ctx *, float *ms, int n);
 
 const char *uvad_last_error(const uvad_ctx *);
 void uvad_destroy(uvad_ctx *);

@@ -32,6 +32,17 @@ def _worker(rank, world, port, n_total, q):
     root = torch.from_numpy(np.stack([np.abs(synth_pcm(1, 480, seed=1000, first=i)[0]).reshape(3, 160).mean(1) for i in range(n_total)])) if r == 0 else None
     got = udist.scatter_rows(root, n_total, r, w, like=torch.zeros(1, 3, dtype=torch.float32))
     assert got.shape[0] == len(idx) and (len(idx) == 0 or torch.equal(got.to(local.dtype), local))
+    # the per-step form bench.py --scatter uses: the root re-orders the corpus ONCE, then scatters views (uneven shards included)
+    pre = udist.preshard_rows(root, n_total, w) if r == 0 else None
+    if r == 0:
+        per = (n_total + w - 1) // w
+        assert tuple(pre.shape) == (w, per, 3)
+        for rr in range(w):
+            assert torch.equal(pre[rr, : udist.shard_count(n_total, rr, w)], root[udist.shard_indices(n_total, rr, w)])
+    buf = torch.full(((n_total + w - 1) // w, 3), -1.0, dtype=torch.float32)
+    for _ in range(2):   # twice into the same receive buffer, as the double-buffered loop does
+        got2 = udist.scatter_rows(pre, n_total, r, w, like=torch.zeros(1, 3, dtype=torch.float32), presharded=True, out=buf)
+        assert got2.shape[0] == len(idx) and (len(idx) == 0 or (got2.data_ptr() == buf.data_ptr() and torch.equal(got2.to(local.dtype), local)))
     full = udist.gather_rows(local, n_total, r, w)
     t = udist.max_over_ranks(float(r + 1))
     udist.barrier()

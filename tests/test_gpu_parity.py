@@ -288,6 +288,27 @@ def test_predict_vad_reference_window_geometry_from_wav(tmp_path):
             assert np.array_equal(r["labels"], labels)
 
 
+def test_predict_vad_without_concurrent_streams_gives_the_same_predictions(tmp_path, monkeypatch):
+    """with streams that never overlap (as with GPU_MAX_HW_QUEUES = 1) predict_vad runs batch after batch and returns
+    the predictions of the pipelined run."""
+    from config.config import load_config
+    from src.scripts import predict_vad
+    from uvad_amd.runtime import VadRuntime
+    cfg = load_config()
+    cfg.model_dict.encoding_dim = 64
+    cfg.weights_scale = 2.0
+    cfg.max_duration = 12
+    cfg.input.kind = "synthetic"
+    cfg.input.num_utterances, cfg.input.seconds, cfg.input.seed = 3, 16.0, 77
+    want = predict_vad(**cfg)
+    monkeypatch.setattr(VadRuntime, "streams_overlap", lambda self, a, b: False)
+    got = predict_vad(**cfg)
+    assert len(got) == len(want) == 3
+    for g, w in zip(got, want):
+        assert g["num_frames"] == w["num_frames"] > 0 and np.array_equal(g["labels"], w["labels"]) and g["intervals"] == w["intervals"]
+        assert np.array_equal(g["probs"], w["probs"])
+
+
 def test_library_is_loaded_and_errors_are_loud():
     import uvad_amd
     from uvad_amd import _lib

@@ -82,6 +82,11 @@ def test_cfg2_full_size_logit_parity(scale):
                 assert st[key] <= REL * st_cpu[key], (mode, key, st[key], st_cpu[key])
             tail = REL if mode == "f16p" else 2 * REL
             assert st["max"] <= tail * st_cpu["max"], (mode, "max", st["max"], st_cpu["max"])
+            # an ABSOLUTE cap beside the relative one (the CPU path's own error must not be able to excuse anything).
+            # Measured on this network over all 256 000 frames (profiles/r02_logit_error_vs_f64.json): fp32 CPU path 6.4e-4, default mode
+            # 5.7e-4, exact-f32 mode 1.5e-3 against the float64 truth.
+            assert st["max"] < (1.0e-3 if mode == "f16p" else 3.0e-3), (mode, "absolute max vs f64", st["max"])
+            assert st["rms"] < 2.0e-5, (mode, "absolute rms vs f64", st["rms"])
             assert st["frames_over_bound"] <= tail * max(st_cpu["frames_over_bound"], 1)
     rt.set_gemm_mode("f16p")
 
@@ -224,15 +229,18 @@ def test_feature_kernel_beside_a_synthetic_mfma_neighbour():
     """tools/burner_probe.py: the feature kernel and the classifier on one stream while a small kernel that loops over MFMAs, an LDS
     read and s_barrier (tools/mfma_burner.hip, built by __graft_entry__.build()) runs on another.  With 64-bit LDS operations in its
     scratch the feature kernel returned wrong frames in every overlapping call (and so does stock rocFFT); with 32-bit operations
-    only it must be bit-identical to its own result obtained alone."""
+    only it must be bit-identical to its own result obtained alone.  The SincNet front end and the whole PyanNet step (forward_wav) are
+    victims too (VERDICT r2 #3), and one of the neighbours is a whole cfg-2 step of another context."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if not os.path.exists(os.path.join(root, "tools", "libburner.so")):
         pytest.skip("tools/libburner.so not built (python -c 'import __graft_entry__ as g; g.build()')")
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "burner_probe.py"), "fbank", "classify"],
-                         capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "burner_probe.py"), "fbank", "classify", "sincnet", "forward_wav"],
+                         capture_output=True, text=True, timeout=900)
     line = [l for l in out.stdout.splitlines() if l.startswith("SUMMARY")]
     assert line, (out.stdout[-1000:], out.stderr[-2000:])
     d = json.loads(line[-1].split(" ", 1)[1])
     print(out.stdout[-600:])
-    assert d == {"fbank": 0, "classify": 0}, d
+    # sincnet.hip still reads 64-bit LDS fragments (ds_read_b64, the class implicated for the feature kernel): it is held to the same
+    # check -- alone, beside the burner, beside a stock f16 GEMM and beside a whole step of another context in flight
+    assert d == {"fbank": 0, "classify": 0, "sincnet": 0, "forward_wav": 0}, d

@@ -209,6 +209,38 @@ def test_main_with_sincnet_feature_extractor(monkeypatch):
     assert np.abs(got - probs.numpy()).max() < 1e-3
 
 
+def test_predict_vad_sincnet_intervals_use_receptive_field_geometry(monkeypatch):
+    """predict_vad(feature_extractor="sincnet") lays the 293-frame rows of the 5 s cuts end to end, keeps
+    get_num_frames(16000 * duration) + 1 of them and maps run [k, k2) to seconds through frame centres 270 k + 496 rounded to whole
+    seconds (predict_sincnet.py:331-370, 492-504) -- checked against the walk the reference-generated fixture pins
+    (tests/test_host.py::test_sincnet_frame_time_geometry_matches_the_reference_fixture) and, for the device run-length kernel,
+    against the fixture's own label rows."""
+    import json, os
+    from config.config import load_config
+    from src.scripts import predict_vad
+    from uvad_amd import postprocess as pp
+    from uvad_amd.sincnet import SincNet
+    monkeypatch.setenv("UVAD_FEATURE_EXTRACTOR", "sincnet")
+    cfg = load_config()
+    cfg.input.seconds, cfg.input.num_utterances, cfg.input.seed = 23.7, 2, 500
+    res = predict_vad(**cfg)
+    assert len(res) == 2
+    for r in res:
+        # 4 full cuts + the kept 3.7 s tail padded to 5 s = 5 x 293 frames; get_num_frames(379200) + 1 = 1402 are kept
+        assert r["num_frames"] == SincNet.num_frames(379200) + 1 == 1402
+        want = pp.sincnet_labels_to_intervals(r["labels"], 23.7)          # host walk (pinned by the fixture on the CPU side)
+        assert r["intervals"] == want
+        for s, e in r["intervals"]:
+            assert s == int(s) and 0 <= s < e <= 23.7                      # whole seconds, end clamped at the duration
+        by_shift = pp.labels_to_intervals(r["labels"], cfg.frame_shift)
+        if by_shift:
+            assert r["intervals"] != by_shift                               # 0.02 s per frame is NOT the SincNet frame rate
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sincnet_geometry.json")))
+    for w in g["walks"]:
+        lab = torch.from_numpy(np.frombuffer(w["labels"].encode(), np.uint8) - ord("0")).cuda()
+        assert [list(x) for x in pp.sincnet_labels_to_intervals(lab, w["duration"])] == w["intervals"]
+
+
 def test_sincnet_random_length_sweep_vs_oracle():
     """Ragged waveform lengths around the tile edges of the three stages (85 / 42 / 42 pooled outputs per tile) and
     batch sizes around the persistent-grid boundaries, against the torch-CPU restatement."""

@@ -178,7 +178,7 @@ def test_bench_line_contract_on_the_committed_sample():
     import glob
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = sorted(glob.glob(os.path.join(root, "profiles", "r01_v*_bench.json")))[-1]
+    path = sorted(glob.glob(os.path.join(root, "profiles", "r0*bench.json")))[-1]
     o = json.load(open(path))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -192,3 +192,61 @@ def test_bench_line_contract_on_the_committed_sample():
     c = o["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s"
     assert abs(o["value"] - o["config"]["utterances_per_gpu"] * o["config"]["frames_per_utterance"] * o["n_gpus"] / (o["ms_per_step"] * 1e-3)) / o["value"] < 1e-6
+
+
+def test_predict_vad_pipeline_falls_back_when_streams_do_not_overlap(monkeypatch):
+    """ForwardPipeline raises when it cannot prove `depth` concurrent HIP streams (GPU_MAX_HW_QUEUES = 1, a shared
+    device); predict_vad must then run with fewer batches in flight -- down to batch after batch -- not abort."""
+    from uvad_amd import scripts
+    tried = []
+
+    class NoStreams:
+        def __init__(self, model, device, depth=2, recurrent_tile=0):
+            tried.append(depth)
+            raise RuntimeError(f"only 1 concurrent HIP streams found in 48 tries; lower depth (GPU_MAX_HW_QUEUES?)")
+
+    monkeypatch.setattr(scripts, "ForwardPipeline", NoStreams)
+    assert scripts.open_pipeline(object(), "cuda:0", 3) is None and tried == [3]
+    tried.clear()
+    assert scripts.open_pipeline(object(), "cuda:0", 8) is None and tried == [8, 4, 2]
+
+    class TwoStreams:
+        def __init__(self, model, device, depth=2, recurrent_tile=0):
+            if depth > 2:
+                raise RuntimeError("only 2 concurrent HIP streams found in 48 tries; lower depth (GPU_MAX_HW_QUEUES?)")
+            self.depth = depth
+
+    monkeypatch.setattr(scripts, "ForwardPipeline", TwoStreams)
+    assert scripts.open_pipeline(object(), "cuda:0", 4).depth == 2
+
+    class Broken:
+        def __init__(self, *a, **k):
+            raise RuntimeError("out of memory")
+
+    monkeypatch.setattr(scripts, "ForwardPipeline", Broken)
+    with pytest.raises(RuntimeError, match="out of memory"):   # anything else is not swallowed
+        scripts.open_pipeline(object(), "cuda:0", 3)
+
+
+def test_sincnet_frame_time_geometry_matches_the_reference_fixture():
+    """VERDICT r2 #8.  tests/golden/sincnet_geometry.json holds outputs of the REFERENCE's own code (tools/gen_golden_sincnet_geometry.py:
+    receptive_field.py imported from its file; get_timestamp_from_sample_boundary, the run-length walk of get_new_cuts, the
+    merge / split helpers compiled out of predict_sincnet.py's syntax tree).  Frame k is centred on sample 270 k + 496 (round(0.5 * 991) in Python) and the
+    reference rounds to whole seconds -- it does NOT multiply by frame_shift."""
+    import json
+    from uvad_amd import postprocess as pp
+    from uvad_amd.sincnet import SincNet
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sincnet_geometry.json")))
+    assert [pp.SINC_RF_1, pp.SINC_RF_2] == g["receptive_field"] and pp.SINC_STEP == 270 and pp.SINC_HALF == 496   # the reference's comment says 495, its round(495.5) is 496
+    for n, frames in g["num_frames"].items():
+        assert SincNet.num_frames(int(n)) == frames, n
+    for a, b, d, s, e in g["timestamps"]:
+        assert pp.sincnet_frame_times(a, b, d) == (s, e), (a, b, d)
+    for w in g["walks"]:
+        lab = np.frombuffer(w["labels"].encode(), np.uint8) - ord("0")
+        got = pp.sincnet_labels_to_intervals(lab, w["duration"])
+        assert [list(x) for x in got] == w["intervals"], (w["duration"], got[:4], w["intervals"][:4])
+    for m in g["merge"]:
+        assert pp.merge_intervals_with_buffer(m["intervals"], m["duration"], m["buffer"]) == m["merged"]
+    for m in g["split"]:
+        assert pp.split_into_windows(m["intervals"], m["window"]) == m["split"]

@@ -30,18 +30,24 @@ mw = uvad_amd.PyanNet(); mw.build(); seed_weights(mw, 1234, 4.0); mw = mw.to(dev
 rtw = mw.runtime(dev)
 wav = synth_pcm_device(256, 80000, seed=7, device=dev)
 victims["sincnet"] = lambda: rtw.sincnet(wav)
+victims["forward_wav"] = lambda: rtw.forward_wav(wav, want_probs=False)[0]   # SincNet (64-bit LDS reads) + the classifier, as one pipeline step
+rt2 = uvad_amd.VadRuntime(device=dev, fbank=m._fbank_cfg, model={"encoding_dim": 64, "lstm": m.hparams.lstm, "linear": m.hparams.linear})
+rt2.load_state_dict(m.state_dict())
+rt2.set_recurrent_tile(16)
 A16 = torch.randn(8192, 8192, device=dev, dtype=torch.float16)
 B16 = torch.randn(8192, 8192, device=dev, dtype=torch.float16)
 def aggressor(kind):
     if kind == "burner": lib.burner_launch(0, sink.data_ptr(), 8192, 400, sb.cuda_stream)
     elif kind == "matmul": torch.matmul(A16, B16)       # the stock f16 GEMM of the installed BLAS (MFMA + LDS + barriers)
+    elif kind == "step":                                # a whole cfg-2 step of ANOTHER context (its split-f16 GEMMs and recurrences) in flight
+        rt2.forward(pcm, want_probs=False)
 only = [a for a in sys.argv[1:] if not a.endswith('.so')]
 total_bad = {}
 for vname, fn in victims.items():
     if only and vname not in only: continue
     ref = fn().clone()
     torch.cuda.synchronize(dev)
-    for kind in ("none", "burner", "matmul"):
+    for kind in ("none", "burner", "matmul", "step"):
         bad = 0
         for rep in range(30):
             with torch.cuda.stream(sb):
@@ -50,6 +56,6 @@ for vname, fn in victims.items():
                 outs = [fn() for _ in range(3)]
             torch.cuda.synchronize(dev)
             bad += sum(int(not torch.equal(o, ref)) for o in outs)
-        print(f"victim {vname} beside '{kind}': {bad} wrong of 90")
+        print(f"victim {vname} beside '{kind}': {bad} wrong of 90", flush=True)
         total_bad[vname] = total_bad.get(vname, 0) + bad
 print("SUMMARY", __import__("json").dumps(total_bad))

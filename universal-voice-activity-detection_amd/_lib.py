@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libuvad.so")
 
 UVAD_OK = 0
 ERR_NAMES = {-1: "UVAD_E_ARG", -2: "UVAD_E_HIP", -3: "UVAD_E_STATE", -4: "UVAD_E_WORKSPACE", -5: "UVAD_E_UNSUPPORTED"}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class FbankCfg(C.Structure):
@@ -78,6 +78,7 @@ SIGNATURES = {
     "uvad_streams_overlap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "uvad_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "uvad_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "uvad_get_layer_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "uvad_last_error": (C.c_char_p, [C.c_void_p]),
     "uvad_destroy": (None, [C.c_void_p]),
 }

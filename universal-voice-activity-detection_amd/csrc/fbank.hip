@@ -117,26 +117,9 @@ __device__ __forceinline__ float pcm_at(const void *row, int64_t i) {
     return reinterpret_cast<const float *>(row)[i];
 }
 
-#ifdef UVAD_FB_STAMP   // diagnostic build (tools/fbank_ablate.hip): cycle shares of the stages of one wave
-#define FB_STAMP(i)                                                                        \
-    {                                                                                      \
-        unsigned long long t_;                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                 \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
-        __builtin_amdgcn_sched_barrier(0);                                                 \
-        fb_acc[i] += t_ - fb_prev;                                                         \
-        fb_prev = t_;                                                                      \
-    }
-#else
-#define FB_STAMP(i)
-#endif
 
 template <bool I16>
 __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs a, const float2 *__restrict__ tw512) {
-#ifdef UVAD_FB_STAMP
-    unsigned long long fb_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fb_prev;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(fb_prev)::"memory");
-#endif
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = a.frame_len, sh = a.frame_shift, F = a.n_mels;
     const int raw_pad = (((FR_WG - 1) * sh + L) + 3) & ~3;
@@ -235,8 +218,6 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
         asm volatile("" : "+v"(win[r]), "+v"(tw1[r].x), "+v"(tw1[r].y), "+v"(tw2[r].x), "+v"(tw2[r].y));
     asm volatile("" : "+v"(mst0v), "+v"(mst1));
     __syncthreads();
-
-    FB_STAMP(0)   // [0] tile staging + per-lane constants
     // Per-wave scratch as TWO 4-byte arrays (real / imaginary parts of the transform; later the power of frame A / frame B), never
     // as float2 pairs: every LDS instruction of this kernel is a 32-bit one (ds_read_b32 / ds_read2_b32 / ds_write2_b32 ...).
     // With 64-bit LDS operations (ds_read_b64, ds_write2st64_b64, ...) the kernel returned wrong frames whenever its waves
@@ -284,8 +265,6 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
             re[r] = ((re[r] - mua) - a.preemph * (pa[r] - mua)) * win[r];
             im[r] = has_b ? ((im[r] - mub) - a.preemph * (pbv[r] - mub)) * win[r] : 0.f;
         }
-
-        FB_STAMP(1)   // [1] framing, DC, pre-emphasis, window
         // ---- pass 1: DFT over n1 (n = 64 n1 + p), twiddle W512^(p k1) ----------------------------
         dft8(re, im);
 #pragma unroll
@@ -306,7 +285,6 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
             const float2 v = ZB_GET(lane * ZB_LD + k);
             re[k] = v.x; im[k] = v.y;
         }
-        FB_STAMP(2)   // [2] pass 1 + transpose
         // ---- pass 2: lane (k1, b): DFT over a -> c, twiddle W64^(b c) -----------------------------
         dft8(re, im);
 #pragma unroll
@@ -327,7 +305,6 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
             const float2 v = ZB_GET(lane * ZB_LD + k);
             re[k] = v.x; im[k] = v.y;
         }
-        FB_STAMP(3)   // [3] pass 2 + transpose
         // ---- pass 3: lane (k1, c): DFT over b -> d; Z[k1 + 8c + 64d] -------------------------------
         dft8(re, im);
         wave_lds_fence();
@@ -337,7 +314,6 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
             for (int d = 0; d < 8; ++d) ZB_PUT(lam + 64 * d, re[d], im[d]);
         }
         wave_lds_fence();
-        FB_STAMP(4)   // [4] pass 3 + spectrum to LDS
         // ---- split the two real spectra, power: A = (Z[k] + conj Z[N-k])/2, B = (Z[k] - conj Z[N-k])/(2i)
         // (all reads first, then the power pairs overwrite the scratch)
         {
@@ -358,7 +334,6 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
                 if (d < 4 || lane == 0) ZB_PUT(lane + 64 * d, pw[d].x, pw[d].y);
         }
         wave_lds_fence();
-        FB_STAMP(5)   // [5] split + power
         // ---- mel band sums + log; lane = filter ----------------------------------------------------
         // Uniform trip count (the longest band, zero-padded weights), two bins per LDS instruction: the weights of bins i, i+1
         // are F floats apart (ds_read2_b32), their power pairs adjacent (ds_read2_b64, no alignment requirement).  No clamp of
@@ -387,14 +362,7 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
             }
         }
         wave_lds_fence();
-        FB_STAMP(6)   // [6] mel + log + store
     }
-#ifdef UVAD_FB_STAMP
-    if (lane == 0 && blockIdx.x == 3 && blockIdx.y == 5) {
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.feats) + wave * 8;
-        for (int i = 0; i < 8; ++i) o[i] = fb_acc[i];
-    }
-#endif
 }
 
 }  // namespace

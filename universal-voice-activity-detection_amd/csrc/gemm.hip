@@ -16,11 +16,6 @@ namespace uvad {
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDS_LD = 36;
-#ifdef UVAD_GEMM_ABL_NOSTORE   // diagnostic build (tools/gemm_ablate.hip): interior tiles skip their stores
-#define UVAD_GEMM_ABL_NOSTORE_COND full
-#else
-#define UVAD_GEMM_ABL_NOSTORE_COND false
-#endif
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // Row m of A.  Rows past M (or padded sequences, b >= B) are clamped to row 0: every load in the
@@ -149,9 +144,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a, int mt, int n
             v[r] = ACC[r] + bias;                                                                    \
             if (a.act == 1) v[r] = v[r] >= 0.f ? v[r] : a.leaky_slope * v[r];                        \
         }                                                                                            \
-        if (UVAD_GEMM_ABL_NOSTORE_COND) {                                                            \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(v[r]));             \
-        } else if (full) {                                                                           \
+        if (full) {                                                                                  \
             _Pragma("unroll") for (int r = 0; r < 16; ++r)                                           \
                 crow[(size_t)((r & 3) + 8 * (r >> 2)) * cstride] = v[r];                             \
         } else {                                                                                     \

@@ -134,11 +134,9 @@ __global__ __launch_bounds__(256, NSTAGES == 2 ? (OUT_PLANES ? 2 : UVAD_F16P_OCC
     //      Per wave and k-block: 10 ds_read_b128 and 16 MFMAs (4 products x 2 x 2 tiles); per workgroup 20 KiB through the
     //      vector memory path for 64 MFMAs (the 128 x 64 tile of the first version moved 14 KiB per 32 MFMAs and was bound by
     //      exactly that: TA busy 77-86 %, matrix pipe 65 % inside the k loop).
-#ifndef UVAD_F16P_ABL_NODMA
 #pragma unroll
     for (int p = 0; p < NST - 1; ++p)
         if (p < nkb) issue(p, p);
-#endif
     for (int kt = 0; kt < nkb; ++kt) {
         if constexpr (NST == 2) {
             __syncthreads();   // (hipcc waits vmcnt(0) here) k-block kt has landed for every wave; everyone is done reading k-block kt-1
@@ -148,9 +146,7 @@ __global__ __launch_bounds__(256, NSTAGES == 2 ? (OUT_PLANES ? 2 : UVAD_F16P_OCC
             else __builtin_amdgcn_s_waitcnt(0x0f70);
             __builtin_amdgcn_s_barrier();
         }
-#ifndef UVAD_F16P_ABL_NODMA   // diagnostic builds (tools/stage_times.py --lib): outputs of ablated builds are meaningless
         if (kt + NST - 1 < nkb) issue((kt + NST - 1) % NST, kt + NST - 1);
-#endif
         const unsigned short *st = lds + (kt % NST) * STAGE;
         f16x8 ah[2], al[2], w0[2], w1[2], w2[2];
 #pragma unroll
@@ -164,10 +160,6 @@ __global__ __launch_bounds__(256, NSTAGES == 2 ? (OUT_PLANES ? 2 : UVAD_F16P_OCC
             al[i] = *reinterpret_cast<const f16x8 *>(st + KB_ALO + fa[i]);
             w2[i] = *reinterpret_cast<const f16x8 *>(st + KB_W2 + fw[i]);
         }
-#ifdef UVAD_F16P_ABL_NOMFMA
-        asm volatile("" ::"v"(ah[0]), "v"(al[0]), "v"(ah[1]), "v"(al[1]), "v"(w0[0]), "v"(w1[0]), "v"(w2[0]), "v"(w0[1]), "v"(w1[1]), "v"(w2[1]));
-        continue;
-#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -218,9 +210,6 @@ __global__ __launch_bounds__(256, NSTAGES == 2 ? (OUT_PLANES ? 2 : UVAD_F16P_OCC
 #pragma unroll
             for (int j = 0; j < N4 / 256; ++j) {
                 const int q = tid + 256 * j;
-#ifdef UVAD_F16P_ABL_NOSTORE
-                if (Ct[q * 4] == 12345.678f)
-#endif
                 *reinterpret_cast<float4 *>(dst + (size_t)half * (BM * GT) + (size_t)q * 4) = *reinterpret_cast<const float4 *>(Ct + q * 4);
             }
         }

@@ -44,38 +44,24 @@ __device__ __forceinline__ float rcp_nr(float d) {
     return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
 }
 __device__ __forceinline__ float sigmoid_f(float x) {
-#ifdef UVAD_FAST_GATES   // diagnostic A/B (tools/err_probe.py): the round-1 forms
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-L2E * x));
-#else
     // exponent clamped so that 1 + e stays finite (sigmoid(-87) = 1.6e-38 either way)
     const float e = __builtin_amdgcn_exp2f(__builtin_fminf(-L2E * x, 126.0f));
     return rcp_nr(1.0f + e);
-#endif
 }
 __device__ __forceinline__ float tanh_f(float x) {
-#ifdef UVAD_FAST_GATES
-    return __builtin_fmaf(2.0f, sigmoid_f(2.0f * x), -1.0f);
-#else
     const float e = __builtin_amdgcn_exp2f((-2.0f * L2E) * __builtin_fabsf(x));   // (0, 1]
     const float n = 1.0f - e, d = 1.0f + e;                                       // n exact for e >= 0.5 (Sterbenz)
     const float r = __builtin_amdgcn_rcpf(d);
     float q = n * r;
     q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);                           // correctly rounded n / d up to 2^-46
     return __builtin_copysignf(q, x);
-#endif
 }
 
 // The cell update of one (unit, sequence) pair: g = gate pre-activations (i, f, g, o), c updated in place, returns h.
 __device__ __forceinline__ float lstm_cell(const f32x4 g, float &c) {
-#ifdef UVAD_ABL_NOGATE   // diagnostic build (tools/lstm_ablate.hip): cell update reduced to a few adds
-    const float h = g[0] * 1e-3f + g[1] * 1e-3f;
-    c = g[2] + g[3];
-    return h;
-#else
     const float ig = sigmoid_f(g[0]), fg = sigmoid_f(g[1]), gg = tanh_f(g[2]), og = sigmoid_f(g[3]);
     c = __builtin_fmaf(fg, c, ig * gg);
     return og * tanh_f(c);
-#endif
 }
 
 // Two cell updates at once for the 16-sequence kernel, which is bound by vector-instruction issue (four cells per lane and
@@ -92,10 +78,6 @@ __device__ __forceinline__ f32x2 quot_2(f32x2 n, f32x2 d) {   // n / d, d in [1,
     return __builtin_elementwise_fma(__builtin_elementwise_fma(-d, q, n), r, q);
 }
 __device__ __forceinline__ void lstm_cell2(const f32x4 ga, const f32x4 gb, float &ca, float &cb, float &ha, float &hb) {
-#if defined(UVAD_ABL_NOGATE) || defined(UVAD_FAST_GATES)
-    ha = lstm_cell(ga, ca);
-    hb = lstm_cell(gb, cb);
-#else
     const f32x2 one = {1.0f, 1.0f};
     const f32x2 xi = {ga[0], gb[0]}, xf = {ga[1], gb[1]}, xo = {ga[3], gb[3]};
     f32x2 ai = xi * -L2E, af = xf * -L2E, ao = xo * -L2E;
@@ -114,7 +96,6 @@ __device__ __forceinline__ void lstm_cell2(const f32x4 ga, const f32x4 gb, float
     const f32x2 h = quot_2(one - ec, (one + eo) * (one + ec));                  // sigmoid(o) * |tanh(c)|
     ha = __builtin_copysignf(h[0], c[0]);
     hb = __builtin_copysignf(h[1], c[1]);
-#endif
 }
 
 // Gate prefetch: plain loads into a ring of PD register slots (the time loop is unrolled by PD so
@@ -122,18 +103,8 @@ __device__ __forceinline__ void lstm_cell2(const f32x4 ga, const f32x4 gb, float
 // measured no faster, and it is fragile (hipcc may reuse an asm load's destination before the data
 // lands), so the compiler's own waitcnt bookkeeping is kept.
 __device__ __forceinline__ void gq_load(f32x4 &dst, const float *p) {
-#ifdef UVAD_ABL_NOGMEM   // diagnostic: no global traffic inside the time loop
-    dst = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
-    (void)p;
-#else
     dst = *reinterpret_cast<const f32x4 *>(p);
-#endif
 }
-#ifdef UVAD_ABL_NOGMEM
-#define UVAD_YSTORE(ptr, v) asm volatile("" ::"v"(ptr), "v"(v))
-#else
-#define UVAD_YSTORE(ptr, v) (*(ptr) = (v))
-#endif
 
 // h_t -> the two f16 planes the next layer's f16p GEMM reads (gemm_f16p.hip: a ~= hi + lo * 2^-11; |h| < 1, so both pieces are
 // far inside the f16 range)
@@ -206,20 +177,6 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
     }
 
     float hlast = 0.0f;
-#ifdef UVAD_STAMP   // diagnostic build (tools/lstm_ablate.hip): per-wave cycle shares of a step
-    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0;
-#define UVAD_STAMP_AT(i)                                                                          \
-    {                                                                                             \
-        unsigned long long t_;                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        if (st_prev) st_acc[i] += t_ - st_prev;                                                   \
-        st_prev = t_;                                                                             \
-    }
-#else
-#define UVAD_STAMP_AT(i)
-#endif
 
     // Time loop unrolled by the prefetch depth: step s uses ring slot s % PD and refills it with the
     // gates of step s + PD, so every load lands in the register it is consumed from PD steps later
@@ -244,31 +201,18 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
         const float *hb = &hbuf[s & 1][jb][0];
         constexpr int HR = UVAD_LSTM_HR;
         float4 hv[HR];
-#ifdef UVAD_ABL_NOLDSREAD   // diagnostic: no h reads at all (results meaningless)
-#pragma unroll
-        for (int kq = 0; kq < HR; ++kq) hv[kq] = make_float4(c, hlast, c * 0.5f, hlast * 0.5f);
-#else
 #pragma unroll
         for (int kq = 0; kq < HR; ++kq) hv[kq] = *reinterpret_cast<const float4 *>(hb + 4 * kq);
-#endif
-
-        UVAD_STAMP_AT(3)   // [3] = barrier wait + loop top
         // 4 independent accumulation chains (k mod 4): dependent MFMAs are 4 issues apart
         f32x4 a0 = gq[u], a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f}, a3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kq = 0; kq < H / 4; ++kq) {
             const float4 hq = hv[kq % HR];
-#ifndef UVAD_ABL_NOLDSREAD
             if (kq + HR < H / 4) hv[kq % HR] = *reinterpret_cast<const float4 *>(hb + 4 * (kq + HR));
-#endif
-#ifndef UVAD_ABL_NOMFMA
             a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * kq + 0], hq.x, a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * kq + 1], hq.y, a1, 0, 0, 0);
             a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * kq + 2], hq.z, a2, 0, 0, 0);
             a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * kq + 3], hq.w, a3, 0, 0, 0);
-#else
-            a0[0] += w[4 * kq] * hq.x;   // keeps W and h alive without the matrix pipe
-#endif
             if (kq == H / 8) {
                 // refill this ring slot with the gates of step min(s + PD, T - 1) (branch-free: a
                 // redundant re-load of the last row is harmless)
@@ -286,33 +230,20 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * HR, 0);
-        UVAD_STAMP_AT(0)   // [0] = h reads + MFMA chains
         hlast = lstm_cell((a0 + a1) + (a2 + a3), c);
         hbuf[(s + 1) & 1][jb][unit] = hlast;
         if constexpr (PLANES) {
             // K-blocked plane (uvad_internal.h plane_index): the 4 sequence rows x 16 units of a wave are 128 contiguous bytes
-#ifndef UVAD_ABL_NOGMEM
             const size_t R = rowu + (size_t)t * SEQ_TILE;
             const size_t yo = (R >> 7) * y_tile + y_wave + (R & 127) * 16 + y_lane;
             store_planes(a.Yh + yo, a.Yl + yo, hlast);
-#endif
         } else {
-            UVAD_YSTORE(a.Y + (row0 + (size_t)t * SEQ_TILE) * a.ldy + ycol, hlast);
+            *(a.Y + (row0 + (size_t)t * SEQ_TILE) * a.ldy + ycol) = hlast;
         }
-        UVAD_STAMP_AT(1)   // [1] = cell update + h write/store
-#ifndef UVAD_ABL_NOSYNC
         __syncthreads();
-#endif
       }
     }
 
-#ifdef UVAD_STAMP
-    if (lane == 0) {
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(a.hN) + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave) * 4;
-        for (int i = 0; i < 4; ++i) o[i] = st_acc[i];
-    }
-    return;
-#endif
     if (a.hN) {
         a.hN[so] = hlast;
         a.cN[so] = c;
@@ -341,18 +272,6 @@ constexpr int R16_HB_ELEMS = 2 * 2 * 16 * R16_HP;    // [buffer][plane][sequence
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-#ifdef UVAD_R16_STAMP   // diagnostic build: cycle stamps of one wave of workgroup (0, 0) (read back with uvad_debug_stamps)
-__device__ unsigned long long g_r16_stamps[8];
-#define R16_STAMP(i)                                                     \
-    if (stamp_on) {                                                      \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
-        const unsigned long long now = __builtin_readcyclecounter();     \
-        st_acc[i] += now - st_prev;                                      \
-        st_prev = now;                                                   \
-    }
-#else
-#define R16_STAMP(i)
-#endif
 
 template <bool PLANES>
 __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
@@ -448,15 +367,10 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
 
     const unsigned short *p2w = p2 + (size_t)(wave * 16) * 512 + lane * 8;   // fragment (rb, ks) at + (rb*4 + ks) * 512
     const int hfrag = j * R16_HP + 8 * q;                                   // + 32 ks inside a plane
-#ifdef UVAD_R16_STAMP
-    const bool stamp_on = wave == UVAD_R16_STAMP && blockIdx.x == 0 && blockIdx.y == 0;
-    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
-#endif
     for (int s = 0; s < a.T; ++s) {
         const int t = reverse ? a.T - 1 - s : s;
 #pragma unroll
         for (int k = 0; k < 32; ++k) asm volatile("" : "+a"(w[k]));   // P0 / P1 stay in AGPRs (constraint only)
-        R16_STAMP(3)   // [3] = barrier wait (+ loop overhead)
 
         if (s + 1 < a.T) advance(g_p, g_rl, g_in, g_wrap);   // the gates of the next step (the last step re-reads its own)
         const float *gnext = g_p;
@@ -468,7 +382,6 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
             h1[ks] = *reinterpret_cast<const f16x8 *>(hcur + hfrag + 32 * ks);
             h2[ks] = *reinterpret_cast<const f16x8 *>(hcur + 16 * R16_HP + hfrag + 32 * ks);
         }
-        R16_STAMP(0)   // [0] = h fragments read from LDS
         const size_t yrow = row0 + (size_t)t * SEQ_TILE;
         // Row blocks one after the other (16 MFMAs each); the P2 fragment of MFMA group f + 1 is requested from LDS before group f.
         // The kernel is bound by vector-instruction issue (~290 per wave and step: four cell updates per lane), not by the matrix
@@ -497,7 +410,6 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
             gq[rb] = *reinterpret_cast<const f32x4 *>(gnext + 16 * rb);   // next step's gates of this row block: a whole step to arrive
             if (rb & 1) lstm_cell2(gpre[rb - 1], gpre[rb], c[rb - 1], c[rb], hnew[rb - 1], hnew[rb]);   // two cells per packed instruction
         }
-        R16_STAMP(1)   // [1] = MFMAs + cell updates
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const int u = ubase + 4 * rb;
@@ -512,14 +424,9 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
         // h of the PREVIOUS step (complete in LDS since the last barrier, not overwritten before the next one) goes out now,
         // when the fragment registers of this step are dead
         if (s > 0) coop_store(hcur, true);
-        R16_STAMP(2)   // [2] = h split + LDS writes + plane store
         __syncthreads();
     }
     if (a.T > 0) coop_store(hb + (a.T & 1) * (2 * 16 * R16_HP), false);
-#ifdef UVAD_R16_STAMP
-    if (stamp_on && lane == 0)
-        for (int i = 0; i < 4; ++i) g_r16_stamps[i] = st_acc[i];
-#endif
 }
 
 
@@ -621,12 +528,11 @@ hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
         if (tile_used) *tile_used = 16;
         const dim3 grid16((a.tiles + 3) / 4, a.dirs);
         const size_t lds = (size_t)(R16_P2_ELEMS + R16_HB_ELEMS) * sizeof(unsigned short);   // 145 KiB: one workgroup per CU
-        static bool attr_set[2] = {false, false};
-        if (!attr_set[planes]) {
+        {   // the attribute belongs to the (function, device) pair and a process may own contexts on several GPUs (include/uvad.h), so it
+            // is set for the CURRENT device on every launch (as launch_fbank / launch_sinc_conv do; no process-global "done" flag)
             const void *fn = planes ? reinterpret_cast<const void *>(lstm_rec16h_kernel<true>) : reinterpret_cast<const void *>(lstm_rec16h_kernel<false>);
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
-            attr_set[planes] = true;
         }
         if (planes) hipLaunchKernelGGL((lstm_rec16h_kernel<true>), grid16, dim3(512), lds, s, a);
         else hipLaunchKernelGGL((lstm_rec16h_kernel<false>), grid16, dim3(512), lds, s, a);
@@ -649,8 +555,3 @@ hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
 
 }  // namespace uvad
 
-#ifdef UVAD_R16_STAMP
-extern "C" int uvad_debug_stamps(unsigned long long *out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(uvad::g_r16_stamps), 8 * sizeof(unsigned long long));
-}
-#endif

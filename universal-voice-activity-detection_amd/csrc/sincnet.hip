@@ -140,12 +140,6 @@ __global__ __launch_bounds__(WAVES * 64) void conv_pool_kernel(SincConvArgs a) {
             if (x_ >= XW) { x_ -= XW; off_ += (unsigned)(a.Lin - XW); }                    \
         }                                                                                  \
     }
-#ifdef UVAD_SN_ABL_NOSTAGE   // diagnostic builds (tools/sinc_ablate.hip): no input staging at all
-#undef UVAD_SN_PREFETCH
-#define UVAD_SN_PREFETCH(g_) {}
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) pre[e] = 0.f;
-#endif
     UVAD_SN_PREFETCH(g_begin)
 
     int cur_b = -1;
@@ -157,7 +151,6 @@ __global__ __launch_bounds__(WAVES * 64) void conv_pool_kernel(SincConvArgs a) {
             if (tid < a.Cin) nrm[tid] = make_float2(a.in_scale[(size_t)b * a.Cin + tid], a.in_shift[(size_t)b * a.Cin + tid]);
             __syncthreads();
         }
-#ifndef UVAD_SN_ABL_NOSTAGE
         {   // registers -> LDS with the previous stage's instance norm (+ leaky_relu) folded in; branch-free: threads
             // past the window store into a dump slot
             const int x0 = tile * TA * a.stride;
@@ -184,7 +177,6 @@ __global__ __launch_bounds__(WAVES * 64) void conv_pool_kernel(SincConvArgs a) {
             }
             for (int i = tid; i < npad; i += NTHR) xy[nelem + i] = 0.f;   // what the zero-weight padded K steps read
         }
-#endif
         __syncthreads();
         // the next tile's window is fetched now and lands while the matrix cores work on this one
         if (g + 1 < g_end) UVAD_SN_PREFETCH(g + 1)
@@ -205,11 +197,7 @@ __global__ __launch_bounds__(WAVES * 64) void conv_pool_kernel(SincConvArgs a) {
         const int abase = (wave * 32 + li) * a.stride + (CIN1 ? kk : kk * XW);
         int soff = 0, cpair = 0;
         const int chalf = a.Cin >> 1;
-#ifdef UVAD_SN_ABL_NOK      // diagnostic builds: what the tile costs without the K loop
-        const int ksteps = 4;
-#else
         const int ksteps = a.Kp >> 1;
-#endif
         float a0, a1, a2, a3, b0[NT], b1[NT], b2[NT], b3[NT];
 #define UVAD_SN_LOAD(AV, BV, ks_)                                                          \
     {                                                                                      \
@@ -252,17 +240,6 @@ __global__ __launch_bounds__(WAVES * 64) void conv_pool_kernel(SincConvArgs a) {
 #undef UVAD_SN_MFMA
         __syncthreads();   // all A reads of the input window are done: the region becomes the output tile
 
-#ifdef UVAD_SN_ABL_NOEPI    // diagnostic: no epilogue (the accumulators stay live through a never-taken store)
-        {
-            float chk = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) chk += acc[t][r];
-            if (chk == 12345.678f) a.out[tid] = chk;
-            continue;
-        }
-#endif
         // Epilogue in groups of three waves (96 positions = 32 pooled outputs, the size of the LDS output tile): bias,
         // |.|, accumulators -> LDS; 3:1 max pool; coalesced store; and the group's (sum, M2 about its own mean) per
         // channel -- combined in order by norm_finalize_kernel (Chan's update), which keeps the variance accurate when

@@ -983,6 +983,16 @@ int uvad_get_timing(uvad_ctx *c, float ms[5]) {
     return UVAD_OK;
 }
 
+int uvad_get_layer_timing(uvad_ctx *c, float *ms, int n) {
+    if (!c || !ms) return UVAD_E_ARG;
+    if (!c->ev_valid) return fail(c, UVAD_E_STATE, "no timed call recorded");
+    const int L = c->mc.num_layers;
+    if (n < 2 * L) return fail(c, UVAD_E_ARG, "uvad_get_layer_timing: ms holds fewer than 2 * num_layers floats");
+    HIPCHK(c, hipEventSynchronize(c->ev[3]));
+    for (int k = 0; k < 2 * L; ++k) HIPCHK(c, hipEventElapsedTime(&ms[k], c->layer_ev[k], c->layer_ev[k + 1]));
+    return 2 * L;
+}
+
 const char *uvad_last_error(const uvad_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 void uvad_destroy(uvad_ctx *c) {

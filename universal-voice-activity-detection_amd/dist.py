@@ -58,26 +58,45 @@ def gather_rows(local: torch.Tensor, n_total: int, rank: int, world: int) -> Opt
     return out
 
 
-def scatter_rows(full: Optional[torch.Tensor], n_total: int, rank: int, world: int, like: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Root-resident corpus mode: rank 0 holds ``full`` (n_total, ...) and every rank receives the
-    rows of ``shard_indices`` -- one RCCL scatter (root egress over all xGMI links at once; gloo in the CPU tests).
-    ``like`` gives non-root ranks the trailing shape / dtype / device.  Shards are padded to equal length."""
+def preshard_rows(full: torch.Tensor, n_total: int, world: int) -> torch.Tensor:
+    """Root only, ONCE per corpus (not per step): (n_total, ...) rows in utterance order -> (world, per, ...) rank-major, row j of
+    block r = utterance r + j * world (``shard_indices``), short shards zero-padded to per = ceil(n_total / world).  ``scatter_rows``
+    then sends the blocks as they lie (views, no per-call gather of the root-resident corpus)."""
+    per = (n_total + world - 1) // world
+    tail = tuple(full.shape[1:])
+    if n_total == per * world:
+        return full.reshape((per, world) + tail).transpose(0, 1).contiguous()   # one strided pass
+    out = torch.zeros((world, per) + tail, dtype=full.dtype, device=full.device)
+    for r in range(world):
+        n = shard_count(n_total, r, world)
+        out[r, :n] = full[r::world]
+    return out
+
+
+def scatter_rows(full: Optional[torch.Tensor], n_total: int, rank: int, world: int, like: Optional[torch.Tensor] = None,
+                 presharded: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Root-resident corpus mode: rank 0 holds the rows and every rank receives the rows of ``shard_indices`` --
+    one RCCL scatter (root egress over all xGMI links at once; gloo in the CPU tests).  ``full`` on rank 0 is either the
+    (n_total, ...) tensor in utterance order (re-ordered here: one extra pass over the corpus, fine for a one-off) or, with
+    ``presharded=True``, the (world, per, ...) tensor of ``preshard_rows`` -- the per-step form: its blocks are sent as views, the
+    root does no copy.  ``like`` gives non-root ranks the trailing shape / dtype / device; ``out`` (per, ...) reuses a receive
+    buffer.  Shards are padded to equal length; the result is cut to this rank's count."""
     if world == 1:
-        return full
+        return full if not presharded else full[0][:n_total]
     per = (n_total + world - 1) // world
     ref = full if rank == 0 else like
     if ref is None:
         raise ValueError("non-root ranks must pass `like` (a tensor with the row shape, dtype and device)")
-    tail = tuple(ref.shape[1:])
-    recv = torch.empty((per,) + tail, dtype=ref.dtype, device=ref.device)
+    tail = tuple(ref.shape[2:] if (presharded and rank == 0) else ref.shape[1:])
+    recv = out if out is not None else torch.empty((per,) + tail, dtype=ref.dtype, device=ref.device)
+    if tuple(recv.shape) != (per,) + tail:
+        raise ValueError(f"receive buffer {tuple(recv.shape)} != {(per,) + tail}")
     chunks = None
     if rank == 0:
-        chunks = []
-        for r in range(world):
-            idx = shard_indices(n_total, r, world)
-            c = torch.zeros((per,) + tail, dtype=full.dtype, device=full.device)
-            c[: len(idx)] = full[idx]
-            chunks.append(c)
+        blocks = full if presharded else preshard_rows(full, n_total, world)
+        if tuple(blocks.shape[:2]) != (world, per):
+            raise ValueError(f"presharded tensor {tuple(blocks.shape)} is not (world={world}, per={per}, ...)")
+        chunks = list(blocks.unbind(0))
     dist.scatter(recv, chunks, src=0)
     return recv[: shard_count(n_total, rank, world)]
 

@@ -22,8 +22,16 @@ from .runtime import VadRuntime
 class Pending:
     """Result of ForwardPipeline.submit: tensors that are complete once ``result()`` (or ``wait()``) returns."""
 
-    def __init__(self, event, logits, probs):
-        self._event, self._logits, self._probs = event, logits, probs
+    def __init__(self, event, logits, probs, start=None):
+        self._event, self._logits, self._probs, self._start = event, logits, probs, start
+
+    def elapsed_ms(self) -> float:
+        """Device time from the step's first kernel being allowed to start to its last one finishing (submit(timed=True) only):
+        the latency of ONE batch while the other slots' steps share the GPU."""
+        if self._start is None:
+            raise RuntimeError("submit(..., timed=True) to measure a step")
+        self._event.synchronize()
+        return self._start.elapsed_time(self._event)
 
     def wait(self):
         self._event.synchronize()
@@ -47,19 +55,19 @@ class ForwardPipeline:
         self.depth = max(1, int(depth))
         cfg = {"encoding_dim": model.encoding_dim, "lstm": model.hparams.lstm, "linear": model.hparams.linear}
         self.runtimes: List[VadRuntime] = []
-        for _ in range(self.depth):
-            r = VadRuntime(device=self.device, fbank=model._fbank_cfg, model=cfg)
-            r.load_state_dict(model.state_dict())
-            if recurrent_tile:
-                r.set_recurrent_tile(recurrent_tile)
-            self.runtimes.append(r)
         self.streams: Optional[List[torch.cuda.Stream]] = None
         self.streams_tried = 0
         self._k = 0
-        try:
+        try:   # every slot holds a weights copy and (later) a workspace: a failure while building slot k must not leave 0..k-1 behind
+            for _ in range(self.depth):
+                r = VadRuntime(device=self.device, fbank=model._fbank_cfg, model=cfg)
+                self.runtimes.append(r)
+                r.load_state_dict(model.state_dict())
+                if recurrent_tile:
+                    r.set_recurrent_tile(recurrent_tile)
             self.select_streams()
         except Exception:
-            self.close()   # the slots hold device memory: do not leave them behind a failed construction
+            self.close()
             raise
 
     # ------------------------------------------------------------------ streams
@@ -82,18 +90,23 @@ class ForwardPipeline:
         return kept
 
     # ------------------------------------------------------------------ use
-    def submit(self, pcm: torch.Tensor, want_logits: bool = True, want_probs: bool = False) -> Pending:
-        """pcm (B, S) f32 on the device, ready on the CURRENT stream.  Returns at once; the step runs on the next slot's stream."""
+    def submit(self, pcm: torch.Tensor, want_logits: bool = True, want_probs: bool = False, timed: bool = False) -> Pending:
+        """pcm (B, S) f32 on the device, ready on the CURRENT stream.  Returns at once; the step runs on the next slot's stream.
+        timed: bracket the step with timing events on its own stream (Pending.elapsed_ms)."""
         i = self._k % self.depth
         self._k += 1
         s = self.streams[i]
         s.wait_stream(torch.cuda.current_stream(self.device))   # the input was produced on the caller's stream
         with torch.cuda.stream(s):
+            start = None
+            if timed:
+                start = torch.cuda.Event(enable_timing=True)
+                start.record(s)
             logits, probs = self.runtimes[i].forward(pcm, want_logits=want_logits, want_probs=want_probs)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=timed)
             ev.record(s)
         pcm.record_stream(s)
-        return Pending(ev, logits, probs)
+        return Pending(ev, logits, probs, start)
 
     def slot_of_next_submit(self) -> int:
         return self._k % self.depth

@@ -81,6 +81,42 @@ def labels_to_intervals_batch(labels: torch.Tensor, frame_shift: float, runtime=
     return out
 
 
+# ---- SincNet (PyanNet) frames -> seconds, src/scripts/predict_sincnet.py:492-504 ----------------------------------
+SINC_RF_1, SINC_RF_2 = 991, 1261           # receptive field of 1 and of 2 output frames (src/utils/receptive_field.py:197-215)
+SINC_STEP = SINC_RF_2 - SINC_RF_1          # 270 samples between frame centres
+SINC_HALF = round(0.5 * SINC_RF_1)         # the reference's comment says 495; its code, round(495.5), gives 496 (round-half-even) -- the code wins
+
+
+def sincnet_frame_times(start: int, end: int, duration: float, sample_rate: int = 16000):
+    """get_timestamp_from_sample_boundary (predict_sincnet.py:492-504): frame k of the SincNet front end is centred on sample
+    k * 270 + 496 (SINC_HALF); the reference rounds that to WHOLE seconds (Python round), clamps the start at 0 and the end at the
+    recording's duration."""
+    s = round((start * SINC_STEP + SINC_HALF) / sample_rate)
+    e = round((end * SINC_STEP + SINC_HALF) / sample_rate)
+    return max(s, 0), min(e, duration)
+
+
+def sincnet_labels_to_intervals(labels, duration: float, runtime=None) -> List[Tuple[float, float]]:
+    """One recording's 0/1 frame labels (SincNet frame rate) -> [(start_s, end_s)] as get_new_cuts of predict_sincnet.py
+    walks them (:348-370): a run of frames [k, k2) maps through sincnet_frame_times(k, k2 - 1, duration), kept only if
+    end - start > 0.  Labels on the GPU go through uvad_label_runs; host rows are walked with numpy."""
+    if torch.is_tensor(labels) and labels.is_cuda:
+        rt = runtime or _shared_runtime(labels.device)
+        runs, counts = rt.label_runs(labels.reshape(1, -1))
+        n = int(counts.cpu()[0])
+        pairs = runs[0, :n].cpu().numpy()
+    else:
+        v = np.asarray(labels.cpu() if torch.is_tensor(labels) else labels).astype(np.int8).ravel()
+        d = np.diff(np.concatenate(([0], v, [0])))
+        pairs = np.stack([np.flatnonzero(d == 1), np.flatnonzero(d == -1)], axis=1) if v.size else np.zeros((0, 2), np.int64)
+    out = []
+    for k, k2 in pairs:
+        s, e = sincnet_frame_times(int(k), int(k2) - 1, duration)
+        if e - s > 0.0:
+            out.append((s, e))
+    return out
+
+
 # ---- scoring side of get_new_cuts (src/scripts/predict.py:500-509, 612-673) -----------------------------------
 
 def merge_intervals_with_buffer(intervals, total_duration: float, buffer: float):

@@ -84,6 +84,7 @@ class VadRuntime:
             self._check(self.lib.uvad_set_weight(self.ctx, k.encode(), a.ctypes.data, shape, a.ndim))
         self._check(self.lib.uvad_finalize(self.ctx))
         self._finalized = True
+        self._weights_gen = getattr(self, "_weights_gen", 0) + 1   # uvad_finalize re-allocates every weight buffer: graphs captured before are stale
 
     # ------------------------------------------------------------------ helpers
     def _check(self, code):
@@ -253,7 +254,7 @@ class VadRuntime:
             return {"state": state, "ws": ws, "B": B, "chunk": chunk,
                     "out": torch.empty((B, kmax), dtype=torch.float32, device=self.device),
                     "in": torch.empty((B, chunk), dtype=torch.float32, device=self.device),
-                    "graphs": {} if graphs else None}
+                    "graphs": {} if graphs else None, "weights_gen": getattr(self, "_weights_gen", 0)}
 
     def stream_step(self, st, pcm_chunk: "torch.Tensor") -> "torch.Tensor":
         """pcm_chunk (B, chunk) f32 on the GPU -> logits (B, k) of the k frames completed by this chunk (a view of a buffer that
@@ -274,6 +275,9 @@ class VadRuntime:
                                                  out.data_ptr(), out.shape[1], st["ws"].data_ptr(), st["ws"].numel(), self._stream())
 
             graphs = st.get("graphs")
+            if graphs is not None and st.get("weights_gen") != getattr(self, "_weights_gen", 0):
+                graphs.clear()           # captured before a weight hot-swap: their kernel nodes point at freed buffers
+                st["weights_gen"] = getattr(self, "_weights_gen", 0)
             if graphs is None:
                 k = enqueue(pcm_chunk)
             else:
@@ -353,6 +357,15 @@ class VadRuntime:
         buf = (C.c_float * 5)()
         self._check(self.lib.uvad_get_timing(self.ctx, buf))
         return dict(zip(("fbank", "proj", "recurrent", "head", "total"), [float(x) for x in buf]))
+
+    def layer_timing_ms(self):
+        """[(projection ms, recurrence ms)] per LSTM layer of the last timed call."""
+        n = 2 * self._mc_c.num_layers
+        buf = (C.c_float * n)()
+        got = self.lib.uvad_get_layer_timing(self.ctx, buf, n)
+        if got < 0:
+            self._check(got)
+        return [(float(buf[2 * k]), float(buf[2 * k + 1])) for k in range(got // 2)]
 
     # ------------------------------------------------------------------ teardown
     def close(self):

@@ -31,7 +31,8 @@ import torch
 from .engine import VadModel
 from .features import FbankConfig
 from .pipeline import ForwardPipeline
-from .postprocess import labels_to_intervals_batch, median_filter
+from .postprocess import labels_to_intervals_batch, median_filter, sincnet_labels_to_intervals
+from .sincnet import SincNet
 from .synth import seed_weights, synth_pcm
 
 LOG_EPS_PAD = math.log(1e-10)   # lhotse's padding value for log-mel features (LOG_EPSILON)
@@ -65,6 +66,21 @@ def cut_into_windows(num_samples: int, window: int, min_keep: int):
         if n > min_keep:
             out.append((start, n))
     return out
+
+
+def open_pipeline(net, device, depth: int):
+    """ForwardPipeline with as many steps in flight as the device proves concurrent: the constructor raises when it cannot find
+    `depth` pairwise-concurrent HIP streams (GPU_MAX_HW_QUEUES of 1 or 2, a shared or restricted device); fewer steps in flight
+    give the same numbers, so the depth is halved down to 1 and below that the caller runs batch after batch (returns None)."""
+    while depth > 1:
+        try:
+            return ForwardPipeline(net, device, depth=depth)
+        except RuntimeError as e:
+            if "concurrent HIP streams" not in str(e):
+                raise
+            print(f"predict_vad: {e}; continuing with {depth // 2} batch(es) in flight")
+            depth //= 2
+    return None
 
 
 def predict_vad(**kwargs):
@@ -134,8 +150,8 @@ def predict_vad(**kwargs):
 
     rt = net.runtime(device)
     pipe = None
-    if not sincnet and len(batches) > 1:
-        pipe = ForwardPipeline(net, device, depth=min(3, len(batches)))   # kept tails (n < W) take the unfused branch below
+    if not sincnet and len(batches) > 1:   # kept tails (n < W) take the unfused branch below
+        pipe = open_pipeline(net, device, min(3, len(batches)))
 
     def stack(group):
         rows = [recs[pieces[j][0]]["pcm"][pieces[j][1]:pieces[j][1] + pieces[j][2]] for j in group]
@@ -148,6 +164,8 @@ def predict_vad(**kwargs):
         x = stack(group)
         if sincnet:   # (batch, samples); the model consumes raw audio, channel axis added as in vad_engine.py:252-255
             xf = x.float() / 32768.0 if x.dtype == torch.int16 else x
+            if W is not None and n < W:   # a kept tail: the recipe pads the AUDIO cut to the window (.pad(duration=5.0)), so every cut gives 293 frames
+                xf = torch.nn.functional.pad(xf, (0, W - n))
             probs = model(xf.unsqueeze(1)).squeeze(-1)
         elif W is not None and n < W:
             # a kept tail (3 s < length < 5 s): features of the samples that exist, then lhotse's padding frames up to the
@@ -194,10 +212,18 @@ def predict_vad(**kwargs):
             rows_p.append(piece_probs[j])
         labels = torch.cat(rows_l)
         probs = torch.cat(rows_p)
-        if window_s is not None and not sincnet:   # (the SincNet script of the reference, predict_sincnet.py, maps frames by receptive field)
-            keep = min(int(math.ceil(len(r["pcm"]) / sr / frame_shift)) + 1, labels.shape[0])
+        duration = len(r["pcm"]) / sr
+        if sincnet:
+            # predict_sincnet.py:331-336: ceil(get_num_frames(16000 * duration)) + 1 frames of the rows laid end to end; :348-370 +
+            # :492-504: frame index -> seconds by receptive field (step 270 samples, offset round(0.5 * 991) = 496), NOT by frame_shift
+            keep = min(SincNet.num_frames(int(round(sr * duration))) + 1, labels.shape[0])
             labels, probs = labels[:keep], probs[:keep]
-        intervals = labels_to_intervals_batch(labels.unsqueeze(0), frame_shift)[0]   # run-length walk on the GPU (uvad_label_runs)
+            intervals = sincnet_labels_to_intervals(labels, duration)
+        else:
+            if window_s is not None:
+                keep = min(int(math.ceil(duration / frame_shift)) + 1, labels.shape[0])
+                labels, probs = labels[:keep], probs[:keep]
+            intervals = labels_to_intervals_batch(labels.unsqueeze(0), frame_shift)[0]   # run-length walk on the GPU (uvad_label_runs)
         results.append({"recording_id": r["id"], "num_frames": int(labels.shape[0]), "labels": labels.cpu().numpy().astype(np.uint8),
                         "probs": probs.cpu().numpy(), "intervals": intervals})
     results.sort(key=lambda r: r["recording_id"])
