@@ -96,7 +96,7 @@ def test_abi_frame_count_matches_reference_geometry():
     import json, os
     _, _, m = _pair()
     rt = m.runtime(torch.device("cuda:0"))
-    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sincnet_geometry.json")))
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sincnet_predict_geometry.json")))
     for s, n in g["num_frames"].items():
         assert rt.sincnet_num_frames(int(s)) == n, s
     assert rt.sincnet_num_frames(990) == 0
@@ -235,7 +235,7 @@ def test_predict_vad_sincnet_intervals_use_receptive_field_geometry(monkeypatch)
         by_shift = pp.labels_to_intervals(r["labels"], cfg.frame_shift)
         if by_shift:
             assert r["intervals"] != by_shift                               # 0.02 s per frame is NOT the SincNet frame rate
-    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sincnet_geometry.json")))
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sincnet_predict_geometry.json")))
     for w in g["walks"]:
         lab = torch.from_numpy(np.frombuffer(w["labels"].encode(), np.uint8) - ord("0")).cuda()
         assert [list(x) for x in pp.sincnet_labels_to_intervals(lab, w["duration"])] == w["intervals"]

@@ -229,14 +229,14 @@ def test_predict_vad_pipeline_falls_back_when_streams_do_not_overlap(monkeypatch
 
 
 def test_sincnet_frame_time_geometry_matches_the_reference_fixture():
-    """VERDICT r2 #8.  tests/golden/sincnet_geometry.json holds outputs of the REFERENCE's own code (tools/gen_golden_sincnet_geometry.py:
+    """VERDICT r2 #8.  tests/golden/sincnet_predict_geometry.json holds outputs of the REFERENCE's own code (tools/gen_golden_sincnet_predict.py:
     receptive_field.py imported from its file; get_timestamp_from_sample_boundary, the run-length walk of get_new_cuts, the
     merge / split helpers compiled out of predict_sincnet.py's syntax tree).  Frame k is centred on sample 270 k + 496 (round(0.5 * 991) in Python) and the
     reference rounds to whole seconds -- it does NOT multiply by frame_shift."""
     import json
     from uvad_amd import postprocess as pp
     from uvad_amd.sincnet import SincNet
-    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sincnet_geometry.json")))
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sincnet_predict_geometry.json")))
     assert [pp.SINC_RF_1, pp.SINC_RF_2] == g["receptive_field"] and pp.SINC_STEP == 270 and pp.SINC_HALF == 496   # the reference's comment says 495, its round(495.5) is 496
     for n, frames in g["num_frames"].items():
         assert SincNet.num_frames(int(n)) == frames, n

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/sincnet_geometry.json by EXECUTING the reference's own frame -> time code for the SincNet predict
+"""Generate tests/golden/sincnet_predict_geometry.json by EXECUTING the reference's own frame -> time code for the SincNet predict
 path.  Build container only (needs /root/reference); nothing of the reference's text is written anywhere.
 
 What runs:
@@ -99,7 +99,7 @@ def main():
         out["merge"].append({"intervals": iv, "duration": 60, "buffer": buf, "merged": ns["merge_intervals_with_buffer"](iv, 60, buf)})
         out["split"].append({"intervals": [list(x) for x in out["merge"][-1]["merged"]], "window": 10,
                              "split": ns["split_into_windows"]([list(x) for x in out["merge"][-1]["merged"]], window=10)})
-    path = os.path.join(REPO, "tests", "golden", "sincnet_geometry.json")
+    path = os.path.join(REPO, "tests", "golden", "sincnet_predict_geometry.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))
     print(f"{path}: {os.path.getsize(path)} bytes; RF {out['receptive_field']}, 5 s -> {out['num_frames']['80000']} frames")
