@@ -226,6 +226,10 @@ int uvad_forward_wav(uvad_ctx *, const float *d_wav, int B, int64_t S, float *d_
  *      weights (and the bound they put on the feed-forward activations) are checked by uvad_finalize and a context
  *      that fails runs mode 0; features handed to uvad_classify are checked on the device and a batch that fails runs
  *      its first projection in mode 0 (no host synchronisation: both kernels are enqueued, a device flag picks one).
+ *   2  the arithmetic of mode 1 with the tile-streaming kernel (gemm_f16p_kernel) for every GEMM: mode 1 runs the input
+ *      projections of large launches in a weight-stationary persistent kernel (gemm_f16p_ws_kernel: the weight planes of a
+ *      128-column tile stay in registers, only the activation planes stream through LDS) whose output is BIT-IDENTICAL;
+ *      mode 2 exists for A/B measurements and as the reference of that identity test.
  * Both are held to the same 1e-4 logit bound by the tests.  Replaces nothing in the reference (torch picks its GEMM). */
 int uvad_set_gemm_mode(uvad_ctx *, int mode);
 

@@ -91,6 +91,39 @@ def test_cfg2_full_size_logit_parity(scale):
     rt.set_gemm_mode("f16p")
 
 
+@pytest.mark.parametrize("F,lstm,B,T", [(64, None, 256, 1000),                       # cfg 2: K = 64 and K = 256, N = 1024
+                                        (80, None, 37, 611),                         # K = 96 (F = 80 padded), ragged row count
+                                        (64, {"hidden_size": 64}, 61, 509),          # K = 128, N = 512
+                                        (60, {"bidirectional": False}, 130, 300)])   # K = 64 / 128, N = 512, one direction
+def test_weight_stationary_projection_is_bit_identical_to_the_streaming_kernel(F, lstm, B, T):
+    """gemm_f16p_ws_kernel (weights in registers, persistent workgroups pulling row tiles from a queue) issues the same MFMA products
+    in the same order per accumulator as gemm_f16p_kernel: logits and the LSTM / feed-forward taps must be equal bit for bit
+    (mode "f16p" = weight-stationary where the launch is large enough, "f16p_stream" = the tile-streaming kernel everywhere), run after
+    run (the queue hands tiles to workgroups in a different order every time)."""
+    import uvad_amd
+    from uvad_amd.synth import seed_weights
+    dev = torch.device("cuda:0")
+    m = uvad_amd.PyanNet2(lstm=lstm, encoding_dim=F)
+    m.build()
+    seed_weights(m, 1234, 4.0)
+    m = m.to(dev).eval()
+    rt = m.runtime(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    feats = torch.randn(B, T, F, generator=g, device=dev) * 4.0 - 8.0
+    rt.set_gemm_mode("f16p_stream")
+    want, _ = rt.classify(feats, want_probs=False)
+    want = want.clone()
+    y_want, z_want = (t.clone() for t in rt.taps())
+    rt.set_gemm_mode("f16p")
+    for rep in range(3):
+        got, _ = rt.classify(feats, want_probs=False)
+        y, z = rt.taps()
+        assert torch.equal(got, want), (rep, float((got - want).abs().max()))
+        assert torch.equal(y, y_want) and torch.equal(z, z_want)
+    assert torch.isfinite(want).all()
+
+
 def test_cfg3_feature_loop_hipgraph_4096_streams():
     """BASELINE configs[2]: 4096 streams x 1 s chunks, the per-chunk feature loop (100 uvad_fbank launches) captured in ONE
     hipGraph: replay == eager bit for bit, and a 4-stream subset against the float64-DFT C oracle."""

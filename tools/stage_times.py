@@ -9,7 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default=None)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--reps", type=int, default=10)
-ap.add_argument("--mode", default="f16p")
+ap.add_argument("--mode", default="f16p", choices=["f16p", "f16p_stream", "f32"])
 ap.add_argument("--tile", type=int, default=0, help="recurrent form: 0 = by estimated time, 4, 16")
 args = ap.parse_args()
 import uvad_amd
@@ -34,9 +34,4 @@ for _ in range(args.reps):
     for k, v in rt.timing_ms().items():
         acc[k] = acc.get(k, 0.0) + v / args.reps
 print(json.dumps({"lib": args.lib or "default", "mode": args.mode, "batch": args.batch, "tile": rt.recurrent_tile(), "ms": {k: round(v, 4) for k, v in acc.items()}}))
-if hasattr(rt.lib, "uvad_debug_stamps"):   # diagnostic builds with -DUVAD_R16_STAMP=<wave>: cycles per phase of the last launch, per step
-    import ctypes
-    buf = (ctypes.c_ulonglong * 8)()
-    rt.lib.uvad_debug_stamps(buf)
-    T = rt.num_frames(160000)
-    print(json.dumps({"r16_cycles_per_step": {n: round(buf[i] / T, 1) for i, n in enumerate(["h_frag_read", "mfma_and_cells", "h_write_and_store", "barrier"])}}))
+print(json.dumps({"per_layer_ms (projection, recurrence)": [[round(a, 4), round(b, 4)] for a, b in rt.layer_timing_ms()]}))

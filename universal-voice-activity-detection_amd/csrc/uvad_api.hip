@@ -102,7 +102,7 @@ int dev_upload(uvad_ctx *c, const T *host, size_t n, T **out, bool weight = fals
 struct WsLayout {
     int tiles = 0, D = 0, Wd = 0, Fp = 0, Zw = 0;
     size_t M = 0;
-    size_t off_G = 0, off_Y[2] = {0, 0}, off_Z[2] = {0, 0}, off_feats = 0, off_fplanes = 0, off_flag = 0, total = 0;
+    size_t off_G = 0, off_Y[2] = {0, 0}, off_Z[2] = {0, 0}, off_feats = 0, off_fplanes = 0, off_flag = 0, off_ctr = 0, total = 0;
 };
 // Activation buffers hold EITHER f32 rows OR two f16 planes of the same row width (hi plane, then the lo plane): same bytes.
 WsLayout carve(const uvad_ctx *c, int B, int64_t T) {
@@ -122,6 +122,7 @@ WsLayout carve(const uvad_ctx *c, int B, int64_t T) {
     w.off_feats = o; o += align_up((size_t)B * T * (size_t)(c->has_fb && c->fb.n_mels > m.in_dim ? c->fb.n_mels : m.in_dim) * sizeof(float));
     w.off_fplanes = o; o += align_up(Mp * (size_t)w.Fp * sizeof(float));   // f16 planes of the features (split-f16 GEMM mode)
     w.off_flag = o; o += align_up(sizeof(int));   // device-side "features outside the f16 range" flag (uvad_classify)
+    w.off_ctr = o; o += align_up(gemm_f16p_ws_counter_bytes());   // tile-queue counters of the weight-stationary projection kernel
     w.total = o;
     return w;
 }
@@ -610,7 +611,7 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
     auto hi_of = [&](size_t off) { return reinterpret_cast<unsigned short *>(base + off); };
     auto lo_of = [&](size_t off, int width) { return reinterpret_cast<unsigned short *>(base + off) + plane_rows(w.M) * (size_t)width; };
     // the split-f16 GEMM needs operands inside the f16 range: weights were checked by uvad_finalize (f16_ok)
-    const bool f16 = c->gemm_mode == 1 && c->f16_ok;
+    const bool f16 = c->gemm_mode >= 1 && c->f16_ok;
     // the last LSTM layer feeds the classifier kernel directly when there are no feed-forward layers: f32 then
     auto y_planes = [&](int k) { return f16 && (k + 1 < m.num_layers || m.lin_layers > 0); };
     if (c->timing && record_start) HIPCHK(c, hipEventRecord(c->ev[0], s));
@@ -630,7 +631,10 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
             } else {
                 g.Ah = hi_of(w.off_Y[(k - 1) & 1]); g.Al = lo_of(w.off_Y[(k - 1) & 1], w.Wd); g.lda = w.Wd; g.K = w.Wd;
             }
-            HIPCHK(c, launch_gemm_f16p(g, s));
+            if (c->gemm_mode == 1 && gemm_f16p_ws_supported(g, c->n_cu))   // large launches: weights stay in registers, bit-identical gates
+                HIPCHK(c, launch_gemm_f16p_ws(g, reinterpret_cast<unsigned *>(base + w.off_ctr), c->n_cu, s));
+            else
+                HIPCHK(c, launch_gemm_f16p(g, s));
             if (k == 0 && check_range) {   // the same projection by the exact kernel, run only if the flag is set
                 g.A = d_feats; g.lda = m.in_dim; g.a_mode = 1; g.K = L.in; g.gate_run_if_set = 1;
                 HIPCHK(c, launch_gemm(g, s));
@@ -736,7 +740,7 @@ int uvad_get_taps(uvad_ctx *c, int B, int T, float *d_lstm_out, float *d_lin_out
     const char *base = reinterpret_cast<const char *>(ws);
     if (d_lstm_out) {
         const char *y = base + w.off_Y[(m.num_layers - 1) & 1];
-        const bool planes = c->gemm_mode == 1 && c->f16_ok && m.lin_layers > 0;   // what classify_impl made the last layer write
+        const bool planes = c->gemm_mode >= 1 && c->f16_ok && m.lin_layers > 0;   // what classify_impl made the last layer write
         HIPCHK(c, launch_untile(y, planes ? y + plane_rows(w.M) * (size_t)w.Wd * sizeof(unsigned short) : nullptr, w.Wd, w.Wd, d_lstm_out, w.tiles, T, B,
                                 (hipStream_t)stream));
     }
@@ -910,7 +914,7 @@ int uvad_label_runs(uvad_ctx *c, const uint8_t *d_labels, int B, int T, int max_
 
 int uvad_set_gemm_mode(uvad_ctx *c, int mode) {
     if (!c) return UVAD_E_ARG;
-    if (mode < 0 || mode > 1) return fail(c, UVAD_E_ARG, "gemm mode must be 0 (exact f32 MFMA) or 1 (split-f16 x3)");
+    if (mode < 0 || mode > 2) return fail(c, UVAD_E_ARG, "gemm mode must be 0 (exact f32 MFMA), 1 (split-f16 x3) or 2 (split-f16 x3, tile-streaming kernel only)");
     c->gemm_mode = mode;
     return UVAD_OK;
 }

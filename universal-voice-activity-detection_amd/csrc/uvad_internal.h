@@ -71,6 +71,11 @@ hipError_t launch_gemm(const GemmArgs &a, hipStream_t s);
 int gemm_padded_k(int K);        // gemm.hip: K rounded up to its K-step (weight row padding)
 hipError_t launch_gemm_f16p(const GemmArgs &a, hipStream_t s);
 int gemm_f16p_padded_k(int K);   // gemm_f16p.hip: plane row width for a true width K (multiple of 32)
+// gemm_f16p_ws.hip: the same contraction for the tile-blocked gate matrix (c_blocked, no activation) as a weight-stationary persistent
+// kernel; bit-identical output.  `counters` = gemm_f16p_ws_counter_bytes() of device memory (zeroed by the launcher on the stream).
+bool gemm_f16p_ws_supported(const GemmArgs &a, int n_cu);
+size_t gemm_f16p_ws_counter_bytes();
+hipError_t launch_gemm_f16p_ws(const GemmArgs &a, unsigned *counters, int n_cu, hipStream_t s);
 size_t weight_plane_elems(int N, int ldw);
 bool split_weights_f16x3(const float *w, int N, int ldw, unsigned short *out /*3 * weight_plane_elems*/, float *wscale);   // false: not representable
 // canonical f32 features [B][T][F] -> tile-major K-blocked f16 planes (tiles*T*4 rows, Fp columns); *flag (optional) = 1 if a value is non-finite or
