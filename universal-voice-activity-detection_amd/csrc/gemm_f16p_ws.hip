@@ -21,12 +21,16 @@
 //     flight) still balances, and the 8 column tiles of one row tile are pulled by workgroups of the same XCD group around
 //     the same time (the A panel is fetched from HBM once, the other 7 reads hit that XCD's L2);
 //   * the MFMAs are issued with the WEIGHT fragment as the A operand and the activation fragment as B, i.e. they compute the
-//     transposed 32 x 32 block: a lane then holds four CONSECUTIVE gate columns of one row per accumulator quad, so the finished
-//     tile leaves straight from the accumulators as 16-byte stores (16 per wave and tile, four of them complete the 128-byte
-//     line of each of 32 rows), row block by row block, interleaved with the MFMAs of the tile's last k-block.  (Dword stores
-//     in the untransposed layout would be 64 per wave and tile: more than the 6-bit vmcnt lets a wave keep in flight beside
-//     its DMAs.)
-// LDS: NST x 8 KiB (64 KiB at K = 256).  Launches that do not fill the chip, feed-forward layers (f16-plane output) and K outside
+//     transposed 32 x 32 block: a lane then holds four CONSECUTIVE gate columns of one row per accumulator quad, which it
+//     writes with one ds_write_b128 into the wave's own staging image of the finished tile ([128 rows][32 columns] f32, rows
+//     padded to 144 bytes);
+//   * that image leaves during the NEXT tile's k-blocks: 16 pieces of 8 rows x 128 bytes, each one ds_read_b128 and one
+//     16-byte store per lane, so every store instruction writes eight FULL 128-byte lines, one or two per k-block, between
+//     MFMAs, with the non-temporal hint (the gate matrix is read next by another kernel, and 1 GB of it passing through the
+//     L2 evicts the activation panels the other column tiles of the XCD are about to read: K = 64 launch 0.35 -> 0.22 ms).
+//     (Stores straight from the accumulators were measured first: 16-byte pieces of 32 different rows per instruction
+//     -- 0.185 ms of a 0.477 ms K = 256 launch was the store path, nothing of it overlapped.)
+// LDS: NST x 8 KiB ring (64 KiB at K = 256) + 4 x 18 KiB staging.  Launches that do not fill the chip, feed-forward layers (f16-plane output) and K outside
 // {64, 96, 128, 256} stay on gemm_f16p_kernel.
 #include "uvad_internal.h"
 
@@ -39,6 +43,7 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
@@ -62,6 +67,17 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 0xf) | ((N >> 4) << 14));
 }
 
+// The finished tile leaves as NPIECE pieces during the next tile: pieces [piece_begin(kb), piece_begin(kb + 1)) are read from the
+// staging image during k-block kb (kb <= NKB - 2) and stored at the top of k-block kb + 1.
+constexpr int NPIECE = 16;
+template <int NKB> constexpr int piece_begin(int kb) { return kb >= NKB - 1 ? NPIECE : kb <= 0 ? 0 : (NPIECE * kb) / (NKB - 1); }
+// 16-byte stores issued at the top of k-blocks [from, to) of a tile that has a predecessor
+template <int NKB> constexpr int stores_in(int from, int to) {
+    int n = 0;
+    for (int j = from < 1 ? 1 : from; j < to; ++j) n += piece_begin<NKB>(j) - piece_begin<NKB>(j - 1);
+    return n;
+}
+
 // s_waitcnt vmcnt(N) lgkmcnt(0)
 template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {
     static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
@@ -74,9 +90,11 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
     constexpr int NST = Ring<NKB>::NST;
     static_assert(NKB % 2 == 0 && NKB % NST == 0 && NST - 1 <= NKB && NST >= 4, "ring / fragment double-buffer geometry");
     // ALL LDS in one array (a second __shared__ object beside an LDS-DMA ring makes hipcc wait vmcnt(0) before LDS reads):
-    // [NST stages][hi slab | lo slab], then the two tile-queue words
-    __shared__ __attribute__((aligned(16))) unsigned short lds[NST * STAGE + 16];
-    int *qword = reinterpret_cast<int *>(lds + NST * STAGE);
+    // [NST stages][hi slab | lo slab], the four waves' staging images of the finished tile, the tile-queue word
+    constexpr int SG_LD = 36;                    // floats per staged row: 32 + 4 of padding (ds_write_b128 of 8 consecutive rows: no bank conflict)
+    constexpr int SG_WAVE = 128 * SG_LD * 2;     // ushort elements of one wave's image (18 KiB)
+    __shared__ __attribute__((aligned(16))) unsigned short lds[NST * STAGE + 4 * SG_WAVE + 16];
+    int *qword = reinterpret_cast<int *>(lds + NST * STAGE + 4 * SG_WAVE);
 
     if (a.gate && (*a.gate != 0) != (a.gate_run_if_set != 0)) return;   // device-side kernel selection (see GemmArgs)
     const int bid = blockIdx.x, grp = bid & (GROUPS - 1);
@@ -159,10 +177,20 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
 
     f32x16 hi[4], lo[4];
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // Gate matrix: [128-row tile][64-column tile][128][64] f32 (g_index); this wave's 32 columns are one half of a 64-column tile.
-    const size_t g_lane = (size_t)fr * 64 + (wave & 1) * 32 + 4 * fh;
+    // ---- the finished tile.  Staging (per wave): lane (fr, fh) writes accumulator quad q of row block i at row 32 i + fr, floats
+    //      8 q + 4 fh .. + 3.  Piece p (p = 0 .. 15) = rows 8 p .. 8 p + 7: lane l reads row 8 p + (l >> 3), floats 4 (l & 7) .. + 3 and
+    //      stores them at the same place of the gate matrix: [128-row tile][64-column tile][128][64] f32 (g_index), this wave's 32
+    //      columns being one half of a 64-column tile -- eight full 128-byte lines per store instruction.
+    float *sg_w = reinterpret_cast<float *>(lds + NST * STAGE + wave * SG_WAVE) + fr * SG_LD + 4 * fh;
+    const unsigned sg_r = (unsigned)(size_t)(lptr_t)(lds + NST * STAGE + wave * SG_WAVE) + (unsigned)(((lane >> 3) * SG_LD + (lane & 7) * 4) * 4);
+    const size_t g_lane = (size_t)(lane >> 3) * 64 + (wave & 1) * 32 + (lane & 7) * 4;
     const size_t g_ntile = (size_t)n_tile * 2 + (wave >> 1);
     const int n64 = a.N / 64;
+    float *gprev = nullptr;                       // where the staged tile goes
+    f32x4 pc[NPIECE];                            // pieces in flight between their ds_read (k-block kb) and their store (k-block kb + 1)
+#define UVAD_WS_READ_PIECE(p) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pc[p]) : "v"(sg_r), "n"((p) * 8 * SG_LD * 4))
+    static_assert(15 * 8 * SG_LD * 4 < 65536, "DS offset field is 16 bits");
+    static_assert(piece_begin<NKB>(1) <= 6 && NPIECE - piece_begin<NKB>(NKB - 2) <= 6, "at most six pieces per k-block (UVAD_WS_PIECES)");
 
     // One 128-row tile.  FIRST: the workgroup's first tile (no stores of a previous tile among the outstanding operations).
     auto tile = [&](auto first_tag) __attribute__((always_inline)) {
@@ -173,18 +201,24 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
         const int c_n = clampc(c_nxt, c_cur);
         float *gout = a.C + ((size_t)(grp + GROUPS * c_cur) * n64 + g_ntile) * (128 * 64) + g_lane;
         unsigned pulled = 0;
+        (void)pc; (void)sg_r;   // (named outside inline asm too, so that the generic lambdas below capture them)
         static_for<NKB>([&](auto kb_tag) __attribute__((always_inline)) {
             constexpr int kb = decltype(kb_tag)::value;
             constexpr int s = kb & 1, sn = (kb + 1) & 1, stn = (kb + 1) % NST;   // fragment set in use / being filled, stage being read
-            // One wave per SIMD issues everything itself, and the matrix pipe idles while it issues anything else for long: an LDS-DMA
-            // piece costs ~60 cycles of issue, eight fragment reads ~70.  So the k-block is ONE pinned instruction stream (every group
-            // below is fenced with sched_barrier(0); hipcc otherwise sinks the reads to the end and hoists MFMAs over the waits):
-            //     wait + barrier | M M | DMA hi | M M | DMA lo | M M | R R | M M | R R | M M | R R | M M | R R | M M M M
+            // One wave per SIMD issues everything itself, and the matrix pipe idles while it issues anything else for long.  So the
+            // k-block is ONE pinned instruction stream (every group is fenced with sched_barrier(0); hipcc otherwise sinks the reads to the
+            // end and hoists MFMAs over the waits): wait + barrier, then eight MFMA pairs with a GAP after each that takes the wave's
+            // other work: gap 0 the stores of the previous tile's pieces and the first DMA piece, gap 1 the second DMA piece, gaps 1 - 4
+            // two fragment reads each, gap 5 the reads of the staged pieces.  (Assigning the stores and DMA pieces to different gaps
+            // per wave, so that the four waves do not hit the CU's memory path at the same instant, was measured: 0.56 ms against 0.47.)
             // The MFMAs use the fragment set read during the PREVIOUS k-block; the DMA refills the slot of k-block kb - 1; the reads
             // fetch k-block kb + 1 (the next tile's first one at the end).
             // MFMA j of the k-block: A operand = the weight fragment, B operand = the activation fragment, so the 32 x 32 block comes
             // out transposed (a lane holds four consecutive columns of one row); same products and k order as gemm_f16p_kernel:
             //   j = 0..3  hi[i] += P0 . a_hi     4..7  lo[i] += P1 . a_hi     8..11  lo[i] += P0 . a_lo     12..15  lo[i] += P2 . a_hi
+            // The last k-block of a tile runs them row block by row block (j = i, 4 + i, 8 + i, 12 + i) so that a finished row block can be
+            // staged while the next ones are multiplied.
+            constexpr bool LAST = kb == NKB - 1;
             auto M = [&](auto j_tag) __attribute__((always_inline)) {
                 constexpr int j = decltype(j_tag)::value, i = j & 3, p = j >> 2;
                 if constexpr (p == 0) hi[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kb], ah[s][i], kb == 0 ? zero : hi[i], 0, 0, 0);
@@ -192,36 +226,61 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
                 if constexpr (p == 2) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kb], al[s][i], lo[i], 0, 0, 0);
                 if constexpr (p == 3) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[kb], ah[s][i], lo[i], 0, 0, 0);
             };
+            // (hi + lo * 2^-11) * 2^-S + bias into the wave's staging image, four ds_write_b128 per row block.  (The image's previous
+            // content was read during k-blocks 0 .. NKB - 2 of this tile: one wave's LDS operations execute in order.)
+            auto stage_block = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 o;
+                    o.x = __builtin_fmaf(__builtin_fmaf(lo[i][4 * q + 0], 0.00048828125f, hi[i][4 * q + 0]), wscale, bias[4 * q + 0]);
+                    o.y = __builtin_fmaf(__builtin_fmaf(lo[i][4 * q + 1], 0.00048828125f, hi[i][4 * q + 1]), wscale, bias[4 * q + 1]);
+                    o.z = __builtin_fmaf(__builtin_fmaf(lo[i][4 * q + 2], 0.00048828125f, hi[i][4 * q + 2]), wscale, bias[4 * q + 2]);
+                    o.w = __builtin_fmaf(__builtin_fmaf(lo[i][4 * q + 3], 0.00048828125f, hi[i][4 * q + 3]), wscale, bias[4 * q + 3]);
+                    *reinterpret_cast<float4 *>(sg_w + i * (32 * SG_LD) + 8 * q) = o;
+                }
+            };
 #define UVAD_WS_M(j) M(std::integral_constant<int, (j)>{})
 #define UVAD_WS_SB __builtin_amdgcn_sched_barrier(0)
-            // (1) the wave's own pieces of k-block kb + 1 have landed: everything but the DMAs of the NST - 3 k-blocks issued after it
-            //     may still be in flight.  The 16 stores of the previous tile's last k-block sit in that window for kb <= NST - 3 (not in
-            //     the workgroup's first tile): they are counted so that the DMAs behind them stay in flight.  lgkmcnt(0): the fragments
-            //     read during the previous k-block (issued hundreds of cycles ago).
+#define UVAD_WS_PIECE_IF(kb_, t_) \
+    if constexpr (piece_begin<NKB>(kb_) + (t_) < piece_begin<NKB>((kb_) + 1)) UVAD_WS_READ_PIECE(piece_begin<NKB>(kb_) + (t_));
+#define UVAD_WS_STORE_IF(t_)                                                                            \
+    if constexpr (piece_begin<NKB>(kb - 1) + (t_) < piece_begin<NKB>(kb))                               \
+        __builtin_nontemporal_store(pc[piece_begin<NKB>(kb - 1) + (t_)], reinterpret_cast<f32x4 *>(gprev + (size_t)(piece_begin<NKB>(kb - 1) + (t_)) * (8 * 64)));
+            // (1) the wave's own pieces of k-block kb + 1 have landed: everything but what was issued after them may still be in flight --
+            //     the DMAs of the NST - 3 k-blocks in between and the stores of the previous tile's pieces issued in THIS tile's k-blocks
+            //     in that window (stores of the tile before are not counted, nor is anything a wave issues later in the k-block of the
+            //     awaited DMA: the wait is then stricter than needed, never looser).  lgkmcnt(0): the fragments and pieces read during
+            //     the previous k-block.
             UVAD_WS_SB;
-            if (kb <= NST - 3 && !FIRST) wait_vm_lgkm0<2 * (NST - 3) + 16>();
-            else wait_vm_lgkm0<2 * (NST - 3)>();
+            wait_vm_lgkm0<2 * (NST - 3) + (FIRST ? 0 : stores_in<NKB>(kb - (NST - 3), kb))>();
             __builtin_amdgcn_s_barrier();   // ... and everyone's; every wave has k-block kb's fragments in registers, so the slot of kb - 1 is free
             UVAD_WS_SB;
             constexpr int v = kb - 1 + NST;                       // (2) the k-block of the stream that refills that slot
             const int vc = v < NKB ? c_cur : c_n;
             const size_t vt = ((size_t)(grp + GROUPS * vc) * NKB + v % NKB) * SLAB;
             unsigned short *img = lds + ((kb + NST - 1) % NST) * STAGE + wave * 512;
-            if (kb < NKB - 1) {
-                UVAD_WS_M(0); UVAD_WS_M(1); UVAD_WS_SB;
-                __builtin_amdgcn_global_load_lds((gptr_t)(a_hi + vt), (lptr_t)(img), 16, 0, 0);
-                UVAD_WS_SB; UVAD_WS_M(2); UVAD_WS_M(3); UVAD_WS_SB;
-                __builtin_amdgcn_global_load_lds((gptr_t)(a_lo + vt), (lptr_t)(img + SLAB), 16, 0, 0);
-                UVAD_WS_SB; UVAD_WS_M(4); UVAD_WS_M(5); UVAD_WS_SB;
-            } else {
-                // last k-block: row block by row block (MFMA j = i, 4 + i, 8 + i, 12 + i), so that a finished row block can leave while the
-                // next ones are multiplied
-                UVAD_WS_M(0); UVAD_WS_M(4); UVAD_WS_SB;
-                __builtin_amdgcn_global_load_lds((gptr_t)(a_hi + vt), (lptr_t)(img), 16, 0, 0);
-                UVAD_WS_SB; UVAD_WS_M(8); UVAD_WS_M(12); UVAD_WS_SB;
-                __builtin_amdgcn_global_load_lds((gptr_t)(a_lo + vt), (lptr_t)(img + SLAB), 16, 0, 0);
-                UVAD_WS_SB; UVAD_WS_M(1); UVAD_WS_M(5); UVAD_WS_SB;
-            }
+            constexpr int fb = stn * (STAGE * 2);                 // (3) where the fragments of k-block kb + 1 are
+            // what goes into gap g (after MFMA pair g)
+#define UVAD_WS_GAP(g)                                                                                                           \
+    {                                                                                                                            \
+        if constexpr (!FIRST && kb >= 1 && (g) == 0) {   /* the pieces read during k-block kb - 1 leave */                          \
+            UVAD_WS_STORE_IF(0) UVAD_WS_STORE_IF(1) UVAD_WS_STORE_IF(2) UVAD_WS_STORE_IF(3) UVAD_WS_STORE_IF(4) UVAD_WS_STORE_IF(5)          \
+        }                                                                                                                        \
+        if constexpr ((g) == 0) __builtin_amdgcn_global_load_lds((gptr_t)(a_hi + vt), (lptr_t)(img), 16, 0, 0);                   \
+        if constexpr ((g) == 1) __builtin_amdgcn_global_load_lds((gptr_t)(a_lo + vt), (lptr_t)(img + SLAB), 16, 0, 0);            \
+        if constexpr ((g) == 1) { UVAD_WS_READ(ah[sn][0], fb + 0 * 1024); UVAD_WS_READ(ah[sn][1], fb + 1 * 1024); }              \
+        if constexpr ((g) == 2) { UVAD_WS_READ(ah[sn][2], fb + 2 * 1024); UVAD_WS_READ(ah[sn][3], fb + 3 * 1024); }              \
+        if constexpr ((g) == 3) { UVAD_WS_READ(al[sn][0], fb + SLAB * 2 + 0 * 1024); UVAD_WS_READ(al[sn][1], fb + SLAB * 2 + 1 * 1024); } \
+        if constexpr ((g) == 4) { UVAD_WS_READ(al[sn][2], fb + SLAB * 2 + 2 * 1024); UVAD_WS_READ(al[sn][3], fb + SLAB * 2 + 3 * 1024); } \
+        if constexpr ((g) == 5 && !FIRST && !LAST) {   /* this k-block's share of the previous tile's staged pieces */              \
+            UVAD_WS_PIECE_IF(kb, 0) UVAD_WS_PIECE_IF(kb, 1) UVAD_WS_PIECE_IF(kb, 2) UVAD_WS_PIECE_IF(kb, 3) UVAD_WS_PIECE_IF(kb, 4) UVAD_WS_PIECE_IF(kb, 5) \
+        }                                                                                                                        \
+        if constexpr (LAST && (g) == 2) stage_block(0);                                                                          \
+        if constexpr (LAST && (g) == 4) stage_block(1);                                                                          \
+        if constexpr (LAST && (g) == 6) stage_block(2);                                                                          \
+        if constexpr (LAST && (g) == 7) stage_block(3);                                                                          \
+        UVAD_WS_SB;                                                                                                              \
+    }
             // Thread 0 draws the tile after the next one.  Inline asm with the EXEC mask set inside the statement (no branch around it, so
             // no phi / copy of its result register): the compiler's vmcnt bookkeeping does not see the atomic and never waits for it.
             // Its result is read at kb = NST - 2, behind that k-block's vmcnt wait.
@@ -229,6 +288,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
                 unsigned long long sv;
                 asm volatile("v_cmp_eq_u32_e32 vcc, 0, %2\n\ts_and_saveexec_b64 %1, vcc\n\tglobal_atomic_add %0, %3, %4, off sc0\n\ts_mov_b64 exec, %1"
                              : "=&v"(pulled), "=&s"(sv) : "v"(tid), "v"(ctr), "v"(1u) : "vcc", "memory");
+                UVAD_WS_SB;
             }
             if (kb == NST - 2) {
                 // the atomic was issued before the DMAs of k-blocks 1 .. NST-3 of this tile, which the wait above has left as the only
@@ -236,46 +296,32 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
                 unsigned long long sv;
                 asm volatile("v_cmp_eq_u32_e32 vcc, 0, %1\n\ts_and_saveexec_b64 %0, vcc\n\tds_write_b32 %2, %3\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b64 exec, %0"
                              : "=&s"(sv) : "v"(tid), "v"(q_addr), "v"(pulled) : "vcc", "memory");
-            }
-            // (3) the fragments of k-block kb + 1, two reads per MFMA pair
-            constexpr int fb = stn * (STAGE * 2);
-            if (kb < NKB - 1) {
-                UVAD_WS_READ(ah[sn][0], fb + 0 * 1024); UVAD_WS_READ(ah[sn][1], fb + 1 * 1024); UVAD_WS_SB; UVAD_WS_M(6); UVAD_WS_M(7); UVAD_WS_SB;
-                UVAD_WS_READ(ah[sn][2], fb + 2 * 1024); UVAD_WS_READ(ah[sn][3], fb + 3 * 1024); UVAD_WS_SB; UVAD_WS_M(8); UVAD_WS_M(9); UVAD_WS_SB;
-                UVAD_WS_READ(al[sn][0], fb + SLAB * 2 + 0 * 1024); UVAD_WS_READ(al[sn][1], fb + SLAB * 2 + 1 * 1024); UVAD_WS_SB;
-                UVAD_WS_M(10); UVAD_WS_M(11); UVAD_WS_SB;
-                UVAD_WS_READ(al[sn][2], fb + SLAB * 2 + 2 * 1024); UVAD_WS_READ(al[sn][3], fb + SLAB * 2 + 3 * 1024); UVAD_WS_SB;
-                UVAD_WS_M(12); UVAD_WS_M(13); UVAD_WS_M(14); UVAD_WS_M(15);
-            } else {
-                // (hi + lo * 2^-11) * 2^-S + bias, four 16-byte stores per row block
-                auto store_block = [&](int i) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float4 o;
-                        o.x = __builtin_fmaf(__builtin_fmaf(lo[i][4 * q + 0], 0.00048828125f, hi[i][4 * q + 0]), wscale, bias[4 * q + 0]);
-                        o.y = __builtin_fmaf(__builtin_fmaf(lo[i][4 * q + 1], 0.00048828125f, hi[i][4 * q + 1]), wscale, bias[4 * q + 1]);
-                        o.z = __builtin_fmaf(__builtin_fmaf(lo[i][4 * q + 2], 0.00048828125f, hi[i][4 * q + 2]), wscale, bias[4 * q + 2]);
-                        o.w = __builtin_fmaf(__builtin_fmaf(lo[i][4 * q + 3], 0.00048828125f, hi[i][4 * q + 3]), wscale, bias[4 * q + 3]);
-                        *reinterpret_cast<float4 *>(gout + (size_t)i * (32 * 64) + 8 * q) = o;
-                    }
-                };
-                UVAD_WS_READ(ah[sn][0], fb + 0 * 1024); UVAD_WS_READ(ah[sn][1], fb + 1 * 1024); UVAD_WS_SB; UVAD_WS_M(9); UVAD_WS_M(13); UVAD_WS_SB;
-                UVAD_WS_READ(ah[sn][2], fb + 2 * 1024); UVAD_WS_READ(ah[sn][3], fb + 3 * 1024); UVAD_WS_SB; UVAD_WS_M(2); UVAD_WS_M(6); UVAD_WS_SB;
-                UVAD_WS_READ(al[sn][0], fb + SLAB * 2 + 0 * 1024); UVAD_WS_READ(al[sn][1], fb + SLAB * 2 + 1 * 1024); UVAD_WS_SB;
-                UVAD_WS_M(10); UVAD_WS_M(14); UVAD_WS_SB;
-                UVAD_WS_READ(al[sn][2], fb + SLAB * 2 + 2 * 1024); UVAD_WS_READ(al[sn][3], fb + SLAB * 2 + 3 * 1024); UVAD_WS_SB;
-                // row block 0 leaves under the MFMAs of row block 3, then 1 and 2; row block 3 is the exposed tail
-                UVAD_WS_M(3); UVAD_WS_M(7); UVAD_WS_M(11); UVAD_WS_M(15);
-                store_block(0);
                 UVAD_WS_SB;
-                store_block(1);
-                store_block(2);
-                store_block(3);
+            }
+            if constexpr (!LAST) {
+                UVAD_WS_M(0); UVAD_WS_M(1); UVAD_WS_SB; UVAD_WS_GAP(0)
+                UVAD_WS_M(2); UVAD_WS_M(3); UVAD_WS_SB; UVAD_WS_GAP(1)
+                UVAD_WS_M(4); UVAD_WS_M(5); UVAD_WS_SB; UVAD_WS_GAP(2)
+                UVAD_WS_M(6); UVAD_WS_M(7); UVAD_WS_SB; UVAD_WS_GAP(3)
+                UVAD_WS_M(8); UVAD_WS_M(9); UVAD_WS_SB; UVAD_WS_GAP(4)
+                UVAD_WS_M(10); UVAD_WS_M(11); UVAD_WS_SB; UVAD_WS_GAP(5)
+                UVAD_WS_M(12); UVAD_WS_M(13); UVAD_WS_SB; UVAD_WS_GAP(6)
+                UVAD_WS_M(14); UVAD_WS_M(15); UVAD_WS_SB; UVAD_WS_GAP(7)
+            } else {
+                UVAD_WS_M(0); UVAD_WS_M(4); UVAD_WS_SB; UVAD_WS_GAP(0)
+                UVAD_WS_M(8); UVAD_WS_M(12); UVAD_WS_SB; UVAD_WS_GAP(1)
+                UVAD_WS_M(1); UVAD_WS_M(5); UVAD_WS_SB; UVAD_WS_GAP(2)
+                UVAD_WS_M(9); UVAD_WS_M(13); UVAD_WS_SB; UVAD_WS_GAP(3)
+                UVAD_WS_M(2); UVAD_WS_M(6); UVAD_WS_SB; UVAD_WS_GAP(4)
+                UVAD_WS_M(10); UVAD_WS_M(14); UVAD_WS_SB; UVAD_WS_GAP(5)
+                UVAD_WS_M(3); UVAD_WS_M(7); UVAD_WS_SB; UVAD_WS_GAP(6)
+                UVAD_WS_M(11); UVAD_WS_M(15); UVAD_WS_SB; UVAD_WS_GAP(7)
             }
         });
         // the queue word written at kb = NST - 2 was published by the barrier of kb = NST - 1 <= NKB - 1
         int c_nn;   // (a generic-pointer read would be a FLAT load, which hipcc guards with vmcnt(0): the DMA ring would drain once per tile)
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(c_nn) : "v"(q_addr) : "memory");
+        gprev = gout;
         c_cur = c_nxt;
         c_nxt = __builtin_amdgcn_readfirstlane(c_nn);
     };
@@ -283,6 +329,13 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
     // (the counter hands every tile index out once, so a workgroup can never run more than my_tiles tiles: the explicit bound is
     // the exit condition every wave reaches whatever the queue words hold)
     for (int done = 1; done < my_tiles && c_cur < my_tiles; ++done) tile(std::false_type{});
+    // the last tile's image
+    static_for<NPIECE>([&](auto t) __attribute__((always_inline)) {
+        constexpr int p = decltype(t)::value;
+        f32x4 o;
+        asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(o) : "v"(sg_r), "n"(p * 8 * SG_LD * 4) : "memory");
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(gprev + (size_t)p * (8 * 64)));
+    });
     wait_vm<0>();   // no LDS-DMA may still be in flight when the workgroup's LDS is handed to another one
 }
 
