@@ -199,7 +199,7 @@ def main():
     stage["recurrent"]["kernel"] = rec_kernel
     for k in f16_stages:
         if k != "recurrent":
-            stage[k]["kernel"] = "gemm_f16p_kernel" + (" + classifier_kernel" if k == "head" else "")
+            stage[k]["kernel"] = "gemm_f16p_kernel + classifier_kernel" if k == "head" else "gemm_f16p_ws_kernel"
         stage[k]["f32_equivalent_TFLOPs"] = stage[k].pop("achieved_TFLOPs")
         stage[k]["f16_pipe_TFLOPs"] = 4.0 * stage[k]["f32_equivalent_TFLOPs"]
         stage[k]["frac"] = stage[k]["f16_pipe_TFLOPs"] / PEAK_F16_MFMA_TFLOPS
@@ -232,7 +232,7 @@ def main():
         return None, None
     if gemm_cu_ms >= rec_cu_ms:
         kern, dur_ms, flops_launch, peak = alone["proj_kernel"], alone["proj_k256_ms"], gemm_f16_flops, PEAK_F16_MFMA_TFLOPS
-        traffic, traffic_src = quoted_traffic(kern.split("<")[0])
+        traffic, traffic_src = quoted_traffic("gemm_f16p_ws_kernel<16>")
         algo_bytes = Mrows * (K_hid * 2 * 2 + 1024 * 4)     # two f16 planes of A read once + the f32 gate matrix written once
     else:
         kern, dur_ms, flops_launch = rec_kernel, alone["recurrent_launch_ms"], rec_f16_flops
@@ -319,7 +319,7 @@ def alone_on_gpu(rt, dev, pcm, tile):
     nl = len(rows[0])
     proj = [med([r[k][0] for r in rows]) for k in range(nl)]
     rec = [med([r[k][1] for r in rows]) for k in range(nl)]
-    return {"recurrent_tile": used, "proj_kernel": "gemm_f16p_kernel", "proj_layer0_ms": proj[0], "proj_k256_ms": med(proj[1:]) if nl > 1 else proj[0],
+    return {"recurrent_tile": used, "proj_kernel": "gemm_f16p_ws_kernel<16>", "proj_layer0_ms": proj[0], "proj_k256_ms": med(proj[1:]) if nl > 1 else proj[0],
             "recurrent_launch_ms": med(rec), "fbank_ms": med([t["fbank"] for t in tot]), "head_ms": med([t["head"] for t in tot]),
             "step_ms": med([t["total"] for t in tot]),
             "note": "one step submitted alone on one stream; per-launch HIP events recorded by the library on that stream"}
@@ -385,7 +385,7 @@ def sequential_latency(rt, dev, pcm, steps, world, forced=0):
     return {"value": frames / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps_in_flight": 1, "recurrent_tile": used,
             "roofline": {"kernel": "lstm_rec_kernel<128, 8, true>", "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": launch_ms},
-            "projection_roofline": {"kernel": "gemm_f16p_kernel<false, 2>", "bound": "mfma", "achieved": ptf, "peak": PEAK_F16_MFMA_TFLOPS,
+            "projection_roofline": {"kernel": "gemm_f16p_ws_kernel", "bound": "mfma", "achieved": ptf, "peak": PEAK_F16_MFMA_TFLOPS,
                                     "unit": "TFLOP/s", "frac": ptf / PEAK_F16_MFMA_TFLOPS, "avg_launch_ms": proj_ms,
                                     "note": "f16-pipe rate (4 MFMA products per f32-equivalent product), the launch alone on the GPU; average of the "
                                             "K = 64 and the three K = 256 projections"},

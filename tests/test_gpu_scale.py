@@ -277,3 +277,40 @@ def test_feature_kernel_beside_a_synthetic_mfma_neighbour():
     # sincnet.hip still reads 64-bit LDS fragments (ds_read_b64, the class implicated for the feature kernel): it is held to the same
     # check -- alone, beside the burner, beside a stock f16 GEMM and beside a whole step of another context in flight
     assert d == {"fbank": 0, "classify": 0, "sincnet": 0, "forward_wav": 0}, d
+
+
+def test_cfg5_512_feeds_20ms_chunks_equal_offline_and_causal_oracle():
+    """BASELINE configs[4] at its named size: 512 concurrent feeds, 20 ms chunks (320 samples -> 2 frames per step) through
+    uvad_stream_step with carried (h, c): ALL feeds against the offline path on the whole signal (causal model: identical by
+    causality up to which frames share an FFT), a subset of feeds against the causal CPU oracle (the reference's
+    PyanNet2(lstm={"bidirectional": False}) operator sequence on float64-DFT features).  3 s of audio per feed = 150 steps."""
+    import uvad_amd
+    from uvad_amd.synth import seed_weights, synth_pcm_device
+    from oracle import c_oracle as co
+    dev = torch.device("cuda:0")
+    B, chunk, F, S = 512, 320, 64, 16000 * 3
+    m = uvad_amd.PyanNet2(lstm={"bidirectional": False}, encoding_dim=F)
+    m.build()
+    seed_weights(m, 1234, 2.0)
+    m.attach_fbank(uvad_amd.FbankConfig(num_filters=F, window_type="hamming"))
+    m = m.to(dev).eval()
+    rt = m.runtime(dev)
+    x = synth_pcm_device(B, S, seed=2000, device=dev)
+    offline, _ = rt.forward(x)
+    st = rt.stream_open(B, chunk)
+    outs = [rt.stream_step(st, x[:, i * chunk:(i + 1) * chunk].contiguous()).clone() for i in range(S // chunk)]
+    got = torch.cat(outs, dim=1)
+    n = got.shape[1]
+    assert n >= S // 160 - 2 and all(o.shape[1] == 2 for o in outs[1:])           # two frames per 20 ms chunk once the first frame is complete
+    err = float((got - offline[:, :n]).abs().max())
+    print(f"cfg 5: {B} feeds x {S // chunk} steps, {n} frames each: streaming vs offline {err:.2e}")
+    assert torch.isfinite(got).all() and err < LOGIT_TOL
+    # a subset of feeds against the CPU oracle
+    sub = [0, 1, 255, 256, 511]
+    cfg = co.default_fbank_cfg(F)
+    feats = co.fbank(x[sub].cpu().numpy(), cfg, co.window("hamming", 400), co.mel_banks(cfg))
+    sd = {k: v.cpu().numpy() for k, v in m.state_dict().items()}
+    want, _ = co.classify(sd, co.ModelCfg(F, 128, 4, 0, 128, 2, 0.01), feats)
+    e2 = float(np.abs(got[sub].cpu().numpy() - want[:, :n]).max())
+    print(f"cfg 5: 5 feeds vs the causal oracle (float64-DFT features) {e2:.2e}")
+    assert e2 < 5e-4          # end to end from PCM: the two feature stages differ by ~1e-4 in the log domain (weights x2)

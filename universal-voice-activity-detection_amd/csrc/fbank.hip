@@ -133,6 +133,15 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
     const int b = blockIdx.y;
     const int64_t t0 = (int64_t)blockIdx.x * FR_WG;
     const int nfr = (int)((a.T - t0) < FR_WG ? (a.T - t0) : FR_WG);
+    if (b >= a.B) {   // plane output only (the grid covers whole sequence tiles): rows of a padding sequence read as zero
+        for (int i = tid; i < nfr * a.plane_w; i += 256) {
+            const size_t row = ((size_t)(b >> 2) * a.T + (size_t)(t0 + i / a.plane_w)) * SEQ_TILE + (b & 3);
+            const size_t o = plane_index(row, i % a.plane_w, a.plane_w);
+            a.plane_hi[o] = 0;
+            a.plane_lo[o] = 0;
+        }
+        return;
+    }
     const int n_left = a.snip_edges ? 0 : (L - sh) / 2;
     const int64_t s0 = t0 * sh - n_left;
     const int need = (nfr - 1) * sh + L;
@@ -355,9 +364,27 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
             }
             ea += ea2;
             eb += eb2;
-            if (m < F) {
+            // ocml logf (<= 1 ulp), not the 2-ulp-of-log2 __logf: two per lane and frame pair, nothing next to the FFT
+            if (a.plane_hi) {
+                // straight into the operand planes of the first projection GEMM (gemm_f16p.hip: x ~= hi + lo * 2^-11, K-blocked, rows in
+                // tile-major order m = (tile * T + t) * 4 + j): the f32 feature tensor never exists.  Columns [F, plane_w) are zero.
+                if (m < a.plane_w) {
+                    const float va = m < F ? logf(fmaxf(ea, a.log_floor)) : 0.f, vb = m < F ? logf(fmaxf(eb, a.log_floor)) : 0.f;
+                    const size_t row = ((size_t)(b >> 2) * a.T + (size_t)(t0 + fa)) * SEQ_TILE + (b & 3);
+                    const size_t oa = plane_index(row, m, a.plane_w);
+                    const _Float16 ha = (_Float16)va;
+                    a.plane_hi[oa] = __builtin_bit_cast(unsigned short, ha);
+                    a.plane_lo[oa] = __builtin_bit_cast(unsigned short, (_Float16)((va - (float)ha) * 2048.0f));
+                    if (has_b) {
+                        const size_t ob = plane_index(row + SEQ_TILE, m, a.plane_w);
+                        const _Float16 hb = (_Float16)vb;
+                        a.plane_hi[ob] = __builtin_bit_cast(unsigned short, hb);
+                        a.plane_lo[ob] = __builtin_bit_cast(unsigned short, (_Float16)((vb - (float)hb) * 2048.0f));
+                    }
+                }
+            } else if (m < F) {
                 float *o = a.feats + ((size_t)b * a.T + t0 + fa) * F + m;
-                o[0] = logf(fmaxf(ea, a.log_floor));   // ocml logf (<= 1 ulp), not the 2-ulp-of-log2 __logf: two per lane and frame pair, nothing next to the FFT
+                o[0] = logf(fmaxf(ea, a.log_floor));
                 if (has_b) o[F] = logf(fmaxf(eb, a.log_floor));
             }
         }
@@ -407,7 +434,10 @@ hipError_t launch_fbank(const FbankArgs &a, hipStream_t s) {
     if (a.B <= 0 || a.T <= 0) return hipSuccess;
     const size_t lds = fbank_lds_bytes(a);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((a.T + FR_WG - 1) / FR_WG), (unsigned)a.B);
+    if (a.plane_hi && (!a.plane_lo || a.plane_w < a.n_mels || a.plane_w % 16 || a.plane_w > 128)) return hipErrorInvalidValue;
+    const unsigned rows = a.plane_hi ? (unsigned)((a.B + SEQ_TILE - 1) / SEQ_TILE * SEQ_TILE) : (unsigned)a.B;
+    if (rows > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((a.T + FR_WG - 1) / FR_WG), rows);
     const float2 *tw = reinterpret_cast<const float2 *>(a.tab.tw512);
     hipError_t e;
     if (a.pcm_is_i16) {

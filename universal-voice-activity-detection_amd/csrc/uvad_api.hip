@@ -532,7 +532,7 @@ int uvad_sincnet(uvad_ctx *c, const float *d_wav, int B, int64_t S, float *d_fea
 
 static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float *d_logits, float *d_probs,
                          void *ws, size_t ws_bytes, hipStream_t s, bool record_start, bool check_range,
-                         const StreamState *ss, int ld_out);
+                         const StreamState *ss, int ld_out, bool feats_in_planes);
 
 int uvad_forward_wav(uvad_ctx *c, const float *d_wav, int B, int64_t S, float *d_logits, float *d_probs,
                      void *ws, size_t ws_bytes, void *stream) {
@@ -552,7 +552,7 @@ int uvad_forward_wav(uvad_ctx *c, const float *d_wav, int B, int64_t S, float *d
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
     int r = sincnet_impl(c, d_wav, B, S, feats, base + w.total, ws_bytes - w.total, s);
     if (r) return r;
-    return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, w.total, s, false, true, nullptr, 0);
+    return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, w.total, s, false, true, nullptr, 0, false);
 }
 
 int64_t uvad_num_frames(const uvad_ctx *c, int64_t S) {
@@ -566,8 +566,9 @@ size_t uvad_workspace_bytes(const uvad_ctx *c, int B, int64_t T) {
     return carve(c, B, T).total;
 }
 
-static int fbank_impl(uvad_ctx *c, const void *d_pcm, int is_i16, int B, int64_t S, float *d_feats, void *stream) {
-    if (!c || !d_pcm || !d_feats || B <= 0 || S <= 0) return fail(c, UVAD_E_ARG, "uvad_fbank: bad argument");
+static int fbank_impl(uvad_ctx *c, const void *d_pcm, int is_i16, int B, int64_t S, float *d_feats, void *stream,
+                      unsigned short *plane_hi = nullptr, unsigned short *plane_lo = nullptr, int plane_w = 0) {
+    if (!c || !d_pcm || (!d_feats && !plane_hi) || B <= 0 || S <= 0) return fail(c, UVAD_E_ARG, "uvad_fbank: bad argument");
     if (!c->has_fb || !c->tables_set) return fail(c, UVAD_E_STATE, "uvad_fbank: uvad_set_tables has not been called");
     const int64_t T = uvad_num_frames(c, S);
     if (T <= 0) return fail(c, UVAD_E_ARG, "uvad_fbank: input shorter than one frame");
@@ -577,7 +578,7 @@ static int fbank_impl(uvad_ctx *c, const void *d_pcm, int is_i16, int B, int64_t
     a.pcm = d_pcm; a.pcm_is_i16 = is_i16; a.B = B; a.S = S; a.T = T;
     a.frame_len = c->fb.frame_len; a.frame_shift = c->fb.frame_shift; a.n_mels = c->fb.n_mels;
     a.preemph = c->fb.preemph; a.log_floor = c->fb.log_floor; a.remove_dc = c->fb.remove_dc; a.snip_edges = c->fb.snip_edges;
-    a.feats = d_feats;
+    a.feats = d_feats; a.plane_hi = plane_hi; a.plane_lo = plane_lo; a.plane_w = plane_w;
     a.tab.window = c->d_window; a.tab.mel_start = c->d_mel_start; a.tab.mel_len = c->d_mel_len;
     a.tab.mel_w = c->d_mel_w; a.tab.mel_stride = c->mel_stride; a.tab.tw512 = c->d_tw512;
     HIPCHK(c, launch_fbank(a, (hipStream_t)stream));
@@ -596,7 +597,7 @@ int uvad_fbank_i16(uvad_ctx *c, const int16_t *d_pcm, int B, int64_t S, float *d
 // written by range_flag_kernel lets exactly one of them run), so the call stays asynchronous and capturable.
 static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float *d_logits, float *d_probs,
                          void *ws, size_t ws_bytes, hipStream_t s, bool record_start, bool check_range,
-                         const StreamState *ss = nullptr, int ld_out = 0) {
+                         const StreamState *ss = nullptr, int ld_out = 0, bool feats_in_planes = false) {
     const uvad_model_cfg &m = c->mc;
     const WsLayout w = carve(c, B, T);
     if (ws_bytes < w.total) return fail(c, UVAD_E_WORKSPACE, "workspace too small: need " + std::to_string(w.total) + " bytes");
@@ -624,8 +625,9 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k], s));
         if (f16) {
             if (k == 0) {
-                HIPCHK(c, launch_split_features(d_feats, B, T, m.in_dim, w.Fp, w.tiles, hi_of(w.off_fplanes), lo_of(w.off_fplanes, w.Fp),
-                                                check_range ? flag : nullptr, s));
+                if (!feats_in_planes)   // (uvad_forward: the feature kernel has written the planes itself)
+                    HIPCHK(c, launch_split_features(d_feats, B, T, m.in_dim, w.Fp, w.tiles, hi_of(w.off_fplanes), lo_of(w.off_fplanes, w.Fp),
+                                                    check_range ? flag : nullptr, s));
                 g.Ah = hi_of(w.off_fplanes); g.Al = lo_of(w.off_fplanes, w.Fp); g.lda = w.Fp; g.K = w.Fp;
                 if (check_range) { g.gate = flag; g.gate_run_if_set = 0; }
             } else {
@@ -716,9 +718,14 @@ static int forward_impl(uvad_ctx *c, const void *d_pcm, int is_i16, int B, int64
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    int r = fbank_impl(c, d_pcm, is_i16, B, S, feats, stream);
+    // split-f16 GEMM mode: the feature kernel writes the two f16 planes the first projection reads (K-blocked, tile-major rows) and
+    // the f32 feature tensor never exists; exact-f32 mode: f32 features.  (log-mel values are within +-90: no range check.)
+    const bool planes = c->gemm_mode >= 1 && c->f16_ok;
+    unsigned short *ph = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(ws) + w.off_fplanes);
+    int r = planes ? fbank_impl(c, d_pcm, is_i16, B, S, nullptr, stream, ph, ph + plane_rows(w.M) * (size_t)w.Fp, w.Fp)
+                   : fbank_impl(c, d_pcm, is_i16, B, S, feats, stream);
     if (r) return r;
-    return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, ws_bytes, s, false, false);   // log-mel values are within +-90
+    return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, ws_bytes, s, false, false, nullptr, 0, planes);
 }
 
 int uvad_forward(uvad_ctx *c, const float *d_pcm, int B, int64_t S, float *d_logits, float *d_probs,
@@ -856,6 +863,12 @@ int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, vo
     fa.frame_len = L; fa.frame_shift = sh; fa.n_mels = c->fb.n_mels;
     fa.preemph = c->fb.preemph; fa.log_floor = c->fb.log_floor; fa.remove_dc = c->fb.remove_dc; fa.snip_edges = 1;
     fa.feats = feats;
+    const bool planes = c->gemm_mode >= 1 && c->f16_ok;   // as in uvad_forward: features straight into the first projection's operand planes
+    if (planes) {
+        fa.plane_hi = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(cws) + w.off_fplanes);
+        fa.plane_lo = fa.plane_hi + plane_rows(w.M) * (size_t)w.Fp;
+        fa.plane_w = w.Fp;
+    }
     fa.tab.window = c->d_window; fa.tab.mel_start = c->d_mel_start; fa.tab.mel_len = c->d_mel_len;
     fa.tab.mel_w = c->d_mel_w; fa.tab.mel_stride = c->mel_stride; fa.tab.tw512 = c->d_tw512;
     HIPCHK(c, launch_fbank(fa, s));
@@ -864,7 +877,7 @@ int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, vo
     ss.layer_stride = S.layer_stride / sizeof(float);
     const bool timing = c->timing;
     c->timing = false;
-    const int r = classify_impl(c, feats, B, k, d_logits, nullptr, cws, ws_bytes - staging_bytes, s, false, false, &ss, ld_logits);
+    const int r = classify_impl(c, feats, B, k, d_logits, nullptr, cws, ws_bytes - staging_bytes, s, false, false, &ss, ld_logits, planes);
     c->timing = timing;
     return r < 0 ? r : k;
 }

@@ -148,6 +148,10 @@ struct FbankArgs {
     int frame_len, frame_shift, n_mels;
     float preemph, log_floor; int remove_dc, snip_edges;
     float *feats;               // [B][T][n_mels]
+    // Instead of feats (plane_hi != nullptr): the two K-blocked f16 planes of the features (plane_w columns, a multiple of 16, the
+    // columns [n_mels, plane_w) written as zero) with rows in the classifier's tile-major order, padding sequences zeroed: the A
+    // operand of the first projection GEMM (gemm_f16p.hip), bit-identical to what launch_split_features makes of feats
+    unsigned short *plane_hi, *plane_lo; int plane_w;
     FbankTables tab;
 };
 hipError_t launch_fbank(const FbankArgs &a, hipStream_t s);
