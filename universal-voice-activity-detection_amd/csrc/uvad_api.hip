@@ -592,6 +592,38 @@ int uvad_fbank_i16(uvad_ctx *c, const int16_t *d_pcm, int B, int64_t S, float *d
     return fbank_impl(c, d_pcm, 1, B, S, d_feats, stream);
 }
 
+// The feed-forward layers one GEMM each (leaky_relu epilogue): workspace buffers Y[last] -> Z[0] -> Z[1] ...; the last one f32.
+static bool mode_fuses_head(const uvad_ctx *c) { return c->gemm_mode == 1; }   // mode 2 keeps the per-layer kernels (A/B, reference of the tests)
+static int feed_forward_layers(uvad_ctx *c, const WsLayout &w, char *base, int B, int T, bool f16, hipStream_t s) {
+    const uvad_model_cfg &m = c->mc;
+    auto Yf = [&](int i) { return reinterpret_cast<float *>(base + w.off_Y[i]); };
+    auto Zf = [&](int i) { return reinterpret_cast<float *>(base + w.off_Z[i]); };
+    auto hi_of = [&](size_t off) { return reinterpret_cast<unsigned short *>(base + off); };
+    auto lo_of = [&](size_t off, int width) { return reinterpret_cast<unsigned short *>(base + off) + plane_rows(w.M) * (size_t)width; };
+    const int last = (m.num_layers - 1) & 1;
+    const float *cur = Yf(last);
+    int curw = w.Wd;
+    for (int j = 0; j < m.lin_layers; ++j) {
+        GemmArgs g{};
+        g.W = c->lin_w[j]; g.ldw = gemm_padded_k(curw); g.Wsplit16 = c->lin_w_split16[j]; g.wscale = c->lin_w_scale[j]; g.bias = c->lin_b[j];
+        g.M = (int)w.M; g.N = m.lin_hidden; g.B = B; g.T = T; g.act = 1; g.leaky_slope = m.leaky_slope;
+        if (f16) {
+            const size_t in_off = j == 0 ? w.off_Y[last] : w.off_Z[(j - 1) & 1];
+            const int in_w = j == 0 ? w.Wd : w.Zw;
+            g.Ah = hi_of(in_off); g.Al = lo_of(in_off, in_w); g.lda = in_w; g.K = in_w;
+            if (j + 1 < m.lin_layers) { g.out_planes = 1; g.Ch = hi_of(w.off_Z[j & 1]); g.Cl = lo_of(w.off_Z[j & 1], w.Zw); g.ldc = w.Zw; }
+            else { g.C = Zf(j & 1); g.ldc = m.lin_hidden; }
+            HIPCHK(c, launch_gemm_f16p(g, s));
+        } else {
+            g.A = cur; g.lda = curw; g.a_mode = 0; g.K = curw; g.C = Zf(j & 1); g.ldc = m.lin_hidden;
+            HIPCHK(c, launch_gemm(g, s));
+        }
+        cur = Zf(j & 1);
+        curw = m.lin_hidden;
+    }
+    return UVAD_OK;
+}
+
 // check_range: the features come from the caller (or from a front end with learnable scales) and may lie outside the f16
 // range; the split-f16 layer-0 projection is then replaced by the exact-f32 one ON THE DEVICE (both are enqueued, a flag
 // written by range_flag_kernel lets exactly one of them run), so the call stays asynchronous and capturable.
@@ -663,26 +695,27 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
     if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * m.num_layers], s));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
     const int last = (m.num_layers - 1) & 1;
-    const float *cur = Yf(last);
-    int curw = w.Wd;
-    for (int j = 0; j < m.lin_layers; ++j) {
-        GemmArgs g{};
-        g.W = c->lin_w[j]; g.ldw = gemm_padded_k(curw); g.Wsplit16 = c->lin_w_split16[j]; g.wscale = c->lin_w_scale[j]; g.bias = c->lin_b[j];
-        g.M = (int)w.M; g.N = m.lin_hidden; g.B = B; g.T = T; g.act = 1; g.leaky_slope = m.leaky_slope;
-        if (f16) {
-            const size_t in_off = j == 0 ? w.off_Y[last] : w.off_Z[(j - 1) & 1];
-            const int in_w = j == 0 ? w.Wd : w.Zw;
-            g.Ah = hi_of(in_off); g.Al = lo_of(in_off, in_w); g.lda = in_w; g.K = in_w;
-            if (j + 1 < m.lin_layers) { g.out_planes = 1; g.Ch = hi_of(w.off_Z[j & 1]); g.Cl = lo_of(w.off_Z[j & 1], w.Zw); g.ldc = w.Zw; }
-            else { g.C = Zf(j & 1); g.ldc = m.lin_hidden; }
-            HIPCHK(c, launch_gemm_f16p(g, s));
-        } else {
-            g.A = cur; g.lda = curw; g.a_mode = 0; g.K = curw; g.C = Zf(j & 1); g.ldc = m.lin_hidden;
-            HIPCHK(c, launch_gemm(g, s));
+    // The default head (two 128-unit feed-forward layers) in split-f16 mode, large launches: feed-forward layers, classifier and
+    // sigmoid in one kernel (head_fused.hip); the LSTM output planes are read once and nothing but the logits is written.
+    // (uvad_get_taps recomputes the feed-forward output from those planes when it is asked for.)
+    if (f16 && mode_fuses_head(c) && head_fused_supported(w.Wd, m.lin_hidden, m.lin_layers, (long long)w.M, c->n_cu)) {
+        HeadArgs h{};
+        h.Yh = hi_of(w.off_Y[last]); h.Yl = lo_of(w.off_Y[last], w.Wd); h.M = (long long)w.M; h.K1 = w.Wd;
+        h.W1 = c->lin_w_split16[0]; h.W2 = c->lin_w_split16[1]; h.w1scale = c->lin_w_scale[0]; h.w2scale = c->lin_w_scale[1];
+        h.b1 = c->lin_b[0]; h.b2 = c->lin_b[1]; h.wc = c->cls_w; h.bc = c->cls_b; h.slope = m.leaky_slope;
+        h.logits = d_logits; h.probs = d_probs; h.tiles = w.tiles; h.T = T; h.B = B; h.ld_out = ld_out > 0 ? ld_out : T;
+        h.counter = reinterpret_cast<unsigned *>(base + w.off_ctr);
+        HIPCHK(c, launch_head_fused(h, c->n_cu, s));
+        if (c->timing) {
+            HIPCHK(c, hipEventRecord(c->ev[3], s));
+            c->ev_valid = true;
         }
-        cur = Zf(j & 1);
-        curw = m.lin_hidden;
+        return UVAD_OK;
     }
+    int r_ff = feed_forward_layers(c, w, base, B, T, f16, s);
+    if (r_ff) return r_ff;
+    const float *cur = m.lin_layers > 0 ? Zf((m.lin_layers - 1) & 1) : Yf(last);
+    const int curw = m.lin_layers > 0 ? m.lin_hidden : w.Wd;
     ClsArgs q{};
     q.Z = cur; q.ldz = curw; q.K = curw; q.w = c->cls_w; q.b = c->cls_b; q.logits = d_logits; q.probs = d_probs;
     q.tiles = w.tiles; q.T = T; q.B = B; q.ld_out = ld_out > 0 ? ld_out : T;
@@ -753,6 +786,13 @@ int uvad_get_taps(uvad_ctx *c, int B, int T, float *d_lstm_out, float *d_lin_out
     }
     if (d_lin_out) {
         if (m.lin_layers <= 0) return fail(c, UVAD_E_ARG, "model has no feed-forward layers");
+        const bool f16 = c->gemm_mode >= 1 && c->f16_ok;
+        if (f16 && mode_fuses_head(c) && head_fused_supported(w.Wd, m.lin_hidden, m.lin_layers, (long long)w.M, c->n_cu)) {
+            // the fused head keeps the feed-forward activations on chip: recompute them from the LSTM output planes of the last call
+            // (same kernels, same bits as the unfused path)
+            int r = feed_forward_layers(c, w, const_cast<char *>(base), B, T, true, (hipStream_t)stream);
+            if (r) return r;
+        }
         const float *z = reinterpret_cast<const float *>(base + w.off_Z[(m.lin_layers - 1) & 1]);
         HIPCHK(c, launch_untile(z, nullptr, m.lin_hidden, m.lin_hidden, d_lin_out, w.tiles, T, B, (hipStream_t)stream));
     }

@@ -132,6 +132,21 @@ hipError_t launch_der(const uint8_t *pred, const uint8_t *gt, int B, int T, uint
 // one wave that busy-waits `ticks` of the 100 MHz constant clock, then (optionally) stores the waited ticks
 hipError_t launch_spin(unsigned long long ticks, unsigned long long *sink, hipStream_t s);
 
+// ---- head_fused.hip: leaky_relu(y W1^T + b1) -> leaky_relu(. W2^T + b2) -> . w + b -> sigmoid in one kernel (two 128-unit layers, split-f16 mode) ----
+struct HeadArgs {
+    const unsigned short *Yh, *Yl;   // K-blocked f16 planes of the LSTM output (K1 columns), tile-major rows
+    long long M; int K1;             // rows (tiles * T * SEQ_TILE), input width (256 or 128)
+    const unsigned short *W1, *W2;   // three exact f16 planes each (split_weights_f16x3: N = 128 rows, K1 / 128 columns)
+    float w1scale, w2scale;
+    const float *b1, *b2, *wc, *bc;  // biases [128], classifier row [128] and bias [1]
+    float slope;
+    float *logits, *probs;           // canonical [b][t] (b < B only), row stride ld_out; either may be nullptr
+    int tiles, T, B, ld_out;
+    unsigned *counter;               // one word of device memory (zeroed by the launcher)
+};
+bool head_fused_supported(int K1, int lin_hidden, int lin_layers, long long M, int n_cu);
+hipError_t launch_head_fused(const HeadArgs &a, int n_cu, hipStream_t s);
+
 // ---- fbank.hip ----------------------------------------------------------------------------
 struct FbankTables {            // device pointers owned by the ctx
     const float *window;        // [frame_len]
