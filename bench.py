@@ -138,6 +138,17 @@ def main():
         r.set_timing(live_events)
     acc = {"fbank": 0.0, "proj": 0.0, "recurrent": 0.0, "head": 0.0, "total": 0.0}
     n_acc = 0
+    sampler = None
+    if rank == 0:   # shader clock / socket power of this GPU during the timed region (sysfs, a thread that sleeps 20 ms between two file reads)
+        try:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+            from gpu_power import PowerSampler, hwmon_of, bdf_of_torch_device
+            paths = hwmon_of(bdf_of_torch_device(dev.index or 0))
+            if paths.get("freq1_input"):
+                sampler = PowerSampler(paths)
+                sampler.start()
+        except Exception as e:   # sensors are information, never a reason to fail the measurement
+            log(f"no clock / power sensors: {e}")
     torch.cuda.synchronize(dev)
     udist.barrier()
     t0 = time.perf_counter()
@@ -154,6 +165,15 @@ def main():
     torch.cuda.synchronize(dev)
     udist.barrier()
     elapsed = time.perf_counter() - t0
+    clocks = None
+    if sampler is not None:
+        sampler.finish()
+        clocks = sampler.summary(t0, t0 + elapsed)
+        clocks["second_half"] = {k: v for k, v in sampler.summary(t0 + 0.5 * elapsed, t0 + elapsed).items() if k in ("sclk_mhz", "socket_power_w")}
+        clocks["note"] = ("sysfs hwmon of this GPU, sampled every 20 ms inside the timed region. With 12 steps in flight the socket sits at its power "
+                          "cap and the shader clock is throttled (nominal 2400 MHz: the peaks in `roofline` are quoted at the nominal clock); "
+                          "the power controller needs ~0.3 s to settle, so short runs see a higher clock than long ones (second_half = settled part). "
+                          "tools/power_probe.py: the same readings for a matrix-pipe-only kernel and for the exact-f32 mode")
     for i in range(min(n_fly, args.steps) if live_events else 0):
         for name, v in rts[i].timing_ms().items():
             acc[name] += v
@@ -278,6 +298,8 @@ def main():
     out["in_flight_outputs_identical_to_single_call"] = n_wrong == 0
     out["config"]["steps_in_flight"] = n_fly
     out["config"]["recurrent_tile"] = rts[0].recurrent_tile()
+    if clocks is not None:
+        out["clocks_during_timed_region"] = clocks
     out["in_flight_batch_latency_ms"] = {"p50": lat[len(lat) // 2], "max": lat[-1], "min": lat[0],
                                          "what": "device time of ONE batch (first kernel allowed to start -> last kernel done) while the other "
                                                  f"{n_fly - 1} steps share the GPU; sequential.ms_per_step is the same batch alone"}

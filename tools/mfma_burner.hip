@@ -83,6 +83,21 @@ __global__ __launch_bounds__(256) void burn_mix(float *out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+
+// memory-only neighbours: every block streams its own 4 MiB slice of `out` (iters passes): kind 10 writes it, kind 11 reads it
+template <bool WRITE>
+__global__ __launch_bounds__(256) void burn_mem(float *out, int iters) {
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    f32x4 *p = reinterpret_cast<f32x4 *>(out) + (size_t)blockIdx.x * (4u << 20) / 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it)
+        for (int i = threadIdx.x; i < (4 << 20) / 16; i += 256) {
+            if (WRITE) __builtin_nontemporal_store(f32x4{(float)it, 1.f, 2.f, 3.f}, p + i);
+            else acc += __builtin_nontemporal_load(p + i);
+        }
+    if (!WRITE && acc[0] == 12345.678f) out[0] = acc[1];
+}
+
 extern "C" int burner_launch(int kind, float *out, int blocks, int iters, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     if (kind == 0) hipLaunchKernelGGL((burn<4, 28>), dim3(blocks), dim3(256), 0, s, out, iters);        // 64 accumulator registers, 28 KiB (the 128x64 GEMM's shape)
@@ -94,6 +109,8 @@ extern "C" int burner_launch(int kind, float *out, int blocks, int iters, void *
     else if (kind == 6) hipLaunchKernelGGL((burn_mix<28, true, false>), dim3(blocks), dim3(256), 0, s, out, iters);    // MFMA + barrier, LDS allocated but idle
     else if (kind == 7) hipLaunchKernelGGL((burn_mix<28, false, true>), dim3(blocks), dim3(256), 0, s, out, iters);    // MFMA + LDS reads, no barrier
     else if (kind == 8) hipLaunchKernelGGL((burn_mix<28, false, false>), dim3(blocks), dim3(256), 0, s, out, iters);   // MFMA, LDS allocated, nothing else
+    else if (kind == 10) hipLaunchKernelGGL((burn_mem<true>), dim3(blocks), dim3(256), 0, s, out, iters);     // HBM writes only (out: blocks x 4 MiB)
+    else if (kind == 11) hipLaunchKernelGGL((burn_mem<false>), dim3(blocks), dim3(256), 0, s, out, iters);    // HBM reads only
     else hipLaunchKernelGGL((burn_mix<1, true, true>), dim3(blocks), dim3(256), 0, s, out, iters);                     // MFMA + barrier + reads, 1 KiB of LDS
     return (int)hipGetLastError();
 }

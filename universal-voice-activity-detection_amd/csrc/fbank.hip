@@ -196,11 +196,8 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
             if (i < need) *reinterpret_cast<float4 *>(raw + i) = v[it];   // raw is padded to a multiple of 4
         }
     }
-    // mel weights transposed to [bin-in-band][filter] so lane m reads conflict-free
-    for (int i = tid; i < 2 * mel_pairs * F; i += 256) {
-        const int m = i % F, r = i / F;
-        melw[i] = r < a.tab.mel_stride ? a.tab.mel_w[(size_t)m * a.tab.mel_stride + r] : 0.0f;
-    }
+    // mel weights as [bin-in-band][filter] (transposed and zero-padded to whole pairs on the host), so lane m reads conflict-free
+    for (int i = tid; i < 2 * mel_pairs * F; i += 256) melw[i] = a.tab.mel_wt[i];
 
     // ---- per-lane constants -------------------------------------------------------------------
     float win[8];

@@ -45,7 +45,7 @@ struct uvad_ctx {
     std::string err;
     std::map<std::string, HostTensor> host_w;
     // device
-    float *d_window = nullptr, *d_mel_w = nullptr, *d_tw512 = nullptr;
+    float *d_window = nullptr, *d_mel_w = nullptr, *d_mel_wt = nullptr, *d_tw512 = nullptr;
     int *d_mel_start = nullptr, *d_mel_len = nullptr;
     int mel_stride = 0;
     std::vector<LayerDev> layers;
@@ -273,6 +273,11 @@ int uvad_set_tables(uvad_ctx *c, const float *window, const float *mel) {
     if ((r = dev_upload(c, st.data(), st.size(), &c->d_mel_start))) return r;
     if ((r = dev_upload(c, ln.data(), ln.size(), &c->d_mel_len))) return r;
     if ((r = dev_upload(c, w.data(), w.size(), &c->d_mel_w))) return r;
+    const int rows_t = 2 * ((maxlen + 1) / 2);
+    std::vector<float> wt((size_t)rows_t * F, 0.0f);
+    for (int m = 0; m < F; ++m)
+        for (int i = 0; i < ln[m]; ++i) wt[(size_t)i * F + m] = w[(size_t)m * maxlen + i];
+    if ((r = dev_upload(c, wt.data(), wt.size(), &c->d_mel_wt))) return r;
     c->tables_set = true;
     return UVAD_OK;
 }
@@ -580,7 +585,7 @@ static int fbank_impl(uvad_ctx *c, const void *d_pcm, int is_i16, int B, int64_t
     a.preemph = c->fb.preemph; a.log_floor = c->fb.log_floor; a.remove_dc = c->fb.remove_dc; a.snip_edges = c->fb.snip_edges;
     a.feats = d_feats; a.plane_hi = plane_hi; a.plane_lo = plane_lo; a.plane_w = plane_w;
     a.tab.window = c->d_window; a.tab.mel_start = c->d_mel_start; a.tab.mel_len = c->d_mel_len;
-    a.tab.mel_w = c->d_mel_w; a.tab.mel_stride = c->mel_stride; a.tab.tw512 = c->d_tw512;
+    a.tab.mel_w = c->d_mel_w; a.tab.mel_wt = c->d_mel_wt; a.tab.mel_stride = c->mel_stride; a.tab.tw512 = c->d_tw512;
     HIPCHK(c, launch_fbank(a, (hipStream_t)stream));
     return UVAD_OK;
 }
@@ -910,7 +915,7 @@ int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, vo
         fa.plane_w = w.Fp;
     }
     fa.tab.window = c->d_window; fa.tab.mel_start = c->d_mel_start; fa.tab.mel_len = c->d_mel_len;
-    fa.tab.mel_w = c->d_mel_w; fa.tab.mel_stride = c->mel_stride; fa.tab.tw512 = c->d_tw512;
+    fa.tab.mel_w = c->d_mel_w; fa.tab.mel_wt = c->d_mel_wt; fa.tab.mel_stride = c->mel_stride; fa.tab.tw512 = c->d_tw512;
     HIPCHK(c, launch_fbank(fa, s));
     StreamState ss;
     ss.h = reinterpret_cast<float *>(st + S.off_h); ss.c = reinterpret_cast<float *>(st + S.off_c);

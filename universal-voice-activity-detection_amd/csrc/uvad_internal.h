@@ -153,6 +153,7 @@ struct FbankTables {            // device pointers owned by the ctx
     const int *mel_start;       // [n_mels] first bin with non-zero weight
     const int *mel_len;         // [n_mels] number of bins
     const float *mel_w;         // [n_mels][mel_stride] weights (zero padded)
+    const float *mel_wt;        // the same transposed: [2 * ceil(mel_stride / 2)][n_mels] (zero padded), the LDS image of fbank_kernel
     int mel_stride;             // max band length rounded up
     const float *tw512;         // [512][2] (cos, -sin)(2*pi*j/512): forward FFT twiddles
 };
