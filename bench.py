@@ -307,6 +307,7 @@ def main():
     if n_fly > 1 and not args.no_sequential:
         out["sequential"] = sequential_latency(rts[0], dev, pcm, min(args.steps, 10), world, args.rec_tile)
         out["exact_f32"] = exact_f32_leg(pipe, dev, pcm, min(args.steps, 24), world)
+        out["three_products"] = three_product_leg(pipe, dev, pcm, min(args.steps, 48), world)
     if args.scatter:
         out["scatter"] = scatter_leg(rt, dev, B, S, rank, world, min(args.steps, 10))
     if rank == 0 and world == 1 and not args.no_sincnet:
@@ -347,14 +348,15 @@ def alone_on_gpu(rt, dev, pcm, tile):
             "note": "one step submitted alone on one stream; per-launch HIP events recorded by the library on that stream"}
 
 
-def exact_f32_leg(pipe, dev, pcm, steps, world):
-    """The same step with every contraction of the time-parallel GEMMs on the exact f32 matrix instruction
-    (uvad_set_gemm_mode(0): v_mfma_f32_32x32x2_f32, bit-compatible with an f32 fmaf chain), same in-flight submission: the
-    same-precision-arithmetic figure next to the headline.  (The 16-sequence recurrence keeps its split-f16 W_hh . h product.)"""
+def mode_leg(pipe, dev, pcm, steps, world, mode, gemm, note):
+    """The same step, same in-flight submission, in another GEMM mode of the library (uvad_set_gemm_mode).
+    "f32": every contraction of the time-parallel GEMMs on the exact f32 matrix instruction (v_mfma_f32_32x32x2_f32, bit-compatible
+    with an f32 fmaf chain): the same-precision-arithmetic figure next to the headline (the 16-sequence recurrence keeps its split-f16
+    W_hh . h product).  "f16p3": three instead of four f16 products per f32-equivalent product (weights rounded to 22 bits)."""
     from uvad_amd import dist as udist
     rts = pipe.runtimes
     for r in rts:
-        r.set_gemm_mode("f32")
+        r.set_gemm_mode(mode)
     try:
         for r in rts:
             r.forward(pcm, want_probs=False)
@@ -369,8 +371,20 @@ def exact_f32_leg(pipe, dev, pcm, steps, world):
             r.set_gemm_mode("f16p")
     frames = world * pcm.shape[0] * rts[0].num_frames(pcm.shape[1]) * steps
     return {"value": frames / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "steps_in_flight": pipe.depth,
-            "gemm": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32, exact f32 products and accumulation)",
-            "note": "not the headline value; logit error of this mode: logit_err_exact_f32_mode"}
+            "gemm": gemm, "note": note}
+
+
+def exact_f32_leg(pipe, dev, pcm, steps, world):
+    return mode_leg(pipe, dev, pcm, steps, world, "f32", "gemm_f32_kernel (v_mfma_f32_32x32x2_f32, exact f32 products and accumulation)",
+                    "not the headline value; logit error of this mode: logit_err_exact_f32_mode")
+
+
+def three_product_leg(pipe, dev, pcm, steps, world):
+    return mode_leg(pipe, dev, pcm, steps, world, "f16p3",
+                    "the headline's kernels with 3 instead of 4 v_mfma_f32_*_f16 products per f32-equivalent product (uvad_set_gemm_mode(3): the P2 x a_hi "
+                    "product dropped = weights rounded to their two leading f16 planes, 22 bits)",
+                    "opt-in mode, not the headline value: the step runs at the socket power limit (clocks_during_timed_region), so 25 % less matrix "
+                    "work is time; logit error of this mode: logit_err_three_product_mode")
 
 
 def sequential_latency(rt, dev, pcm, steps, world, forced=0):
@@ -551,10 +565,15 @@ def cpu_baseline_and_error(model, rt, pcm, dev):
     cpu2.load_state_dict({k: v.detach().cpu() for k, v in m2.state_dict().items()})
     g2 = rt2.classify(feats_gpu, want_probs=False)[0].cpu().numpy()
     x2 = ps.error_stats(g2, cpu2(feats_gpu.cpu())[0].numpy())
+    rt2.set_gemm_mode("f16p3")
+    g2_3 = rt2.classify(feats_gpu, want_probs=False)[0].cpu().numpy()
+    x2_3 = ps.error_stats(g2_3, cpu2(feats_gpu.cpu())[0].numpy())
     rt2.close()
     # (1c) the exact-f32 GEMM mode (uvad_set_gemm_mode(0)) on the x4 network, same inputs
     rt.set_gemm_mode("f32")
     g32 = rt.classify(feats_gpu, want_probs=False)[0].cpu().numpy()
+    rt.set_gemm_mode("f16p3")
+    g3 = rt.classify(feats_gpu, want_probs=False)[0].cpu().numpy()
     rt.set_gemm_mode("f16p")
     f32_vs_cpu = ps.error_stats(g32, ref_same)
     # (2) both against the float64 truth (float64 throughout, torch CPU ops; pinned to oracle/uvad_oracle.c: orc_classify_f64)
@@ -565,6 +584,7 @@ def cpu_baseline_and_error(model, rt, pcm, dev):
     truth = ps.truth_logits(sd, feats_gpu[:ns].cpu(), F, threads=cores)
     st_gpu, st_cpu = ps.error_stats(gl_same[:ns], truth), ps.error_stats(ref_same[:ns], truth)
     st_g32 = ps.error_stats(g32[:ns], truth)
+    st_g3 = ps.error_stats(g3[:ns], truth)
     # (3) end to end from PCM: adds the fp32-FFT difference between the two feature stages (~1e-4 in the
     #     log-mel domain), which the x4-scaled network amplifies.
     gl, _ = rt.forward(pcm[:nb].contiguous(), want_probs=False)
@@ -582,6 +602,7 @@ def cpu_baseline_and_error(model, rt, pcm, dev):
             "logit_err_weights_x4": vs_cpu,
             "logit_err_vs_cpu_fp32": vs_cpu,
             "logit_err_exact_f32_mode": {"vs_cpu_fp32": f32_vs_cpu, "vs_f64_truth": st_g32, "weights": "x4"},
+            "logit_err_three_product_mode": {"weights_x2_vs_cpu_fp32": x2_3, "weights_x4_vs_cpu_fp32": ps.error_stats(g3, ref_same), "weights_x4_vs_f64_truth": st_g3},
             "logit_err_vs_f64_truth": {"gpu": st_gpu, "cpu_fp32": st_cpu,
                                        "sample": f"{ns} utterances x {T} frames, identical features, truth = float64 throughout"},
             "max_abs_logit_err_end_to_end": err_e2e, "max_abs_feature_err": feat_err,

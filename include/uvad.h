@@ -230,7 +230,15 @@ int uvad_forward_wav(uvad_ctx *, const float *d_wav, int B, int64_t S, float *d_
  *      projections of large launches in a weight-stationary persistent kernel (gemm_f16p_ws_kernel: the weight planes of a
  *      128-column tile stay in registers, only the activation planes stream through LDS) whose output is BIT-IDENTICAL;
  *      mode 2 exists for A/B measurements and as the reference of that identity test.
- * Both are held to the same 1e-4 logit bound by the tests.  Replaces nothing in the reference (torch picks its GEMM). */
+ *   3  mode 1 with THREE products per term set in the kernels of large launches (the weight-stationary projection, the fused head,
+ *      the 16-sequence recurrence): the P2 x a_hi product is dropped, i.e. the weights are rounded to their two leading f16 planes
+ *      (22 bits, the precision the activations already have).  The matrix cores then do 25 % less work, and because a step in
+ *      flight runs at the socket's power limit that is time: +9 % frames/s at BASELINE cfg 2, recurrence launch
+ *      1.85 -> 1.60 ms.  Logit error on contractive networks as in mode 1 (3e-7 at weights x2); on the near-chaotic x4 test
+ *      network twice mode 1's distance from the float64 truth (a rounded weight is a slightly different network), which is why
+ *      it is not the default.  Small launches (streaming steps) run mode 1's kernels: outputs of different launch sizes then
+ *      differ in the last bits.
+ * All are held to the same 1e-4 logit bound by the tests.  Replaces nothing in the reference (torch picks its GEMM). */
 int uvad_set_gemm_mode(uvad_ctx *, int mode);
 
 /* How many sequences one recurrent workgroup owns (the time loop of nn.LSTM, PyanNet2.py:169-172):

@@ -10,6 +10,9 @@ Tolerances.  north_star: per-frame logits within 1e-4 max-abs of the CPU referen
     fp32 CPU path itself is further than that from the float64 truth.  The bound is therefore RELATIVE: the HIP path
     must be as close to the float64 truth as the reference's own fp32 CPU path is (factor 1.5 on rms / mean / p99.9 / max
     over the whole batch), i.e. it may not add error of its own.
+  * the opt-in three-product mode ("f16p3": weights rounded to 22 bits) is held to the same 1e-4 at x1 / x2; on the x4 network its
+    rounded weights are a slightly different network and it is allowed 3 x the fp32 CPU path's distance from the truth in the
+    bulk statistics (measured 1.3-2.0 x; that factor is why it is not the default).
 """
 import ctypes as C
 import numpy as np
@@ -62,8 +65,9 @@ def test_cfg2_full_size_logit_parity(scale):
     assert pin < 1e-6
     st_cpu = ps.error_stats(ref[:n64], truth)
     print("  " + ps.fmt("CPU fp32 vs f64", st_cpu))
-    for mode in ("f16p", "f32"):
+    for mode in ("f16p", "f32", "f16p3"):
         rt.set_gemm_mode(mode)
+        rt.set_recurrent_tile(16 if mode == "f16p3" else 0)   # "f16p3" also changes the 16-sequence recurrence: run that kernel (as the bench does)
         g, _ = rt.classify(feats, want_probs=False)
         g = g.cpu().numpy()
         assert np.isfinite(g).all()
@@ -78,17 +82,19 @@ def test_cfg2_full_size_logit_parity(scale):
             # worst of 256 000 frames, the count beyond 1e-4) of this heavy-tailed error move by 2-3x between two correct fp32
             # evaluations when the features change in their last bit: the default mode is held to REL there as well, the exact-f32
             # mode (not the default: its plain fmaf chains carry more rounding error than the split-f16 products) to 2 x REL.
+            bulk = 3.0 if mode == "f16p3" else REL
             for key in ("rms", "mean", "p99.9"):
-                assert st[key] <= REL * st_cpu[key], (mode, key, st[key], st_cpu[key])
-            tail = REL if mode == "f16p" else 2 * REL
+                assert st[key] <= bulk * st_cpu[key], (mode, key, st[key], st_cpu[key])
+            tail = REL if mode == "f16p" else 2 * REL if mode == "f32" else 4.0
             assert st["max"] <= tail * st_cpu["max"], (mode, "max", st["max"], st_cpu["max"])
             # an ABSOLUTE cap beside the relative one (the CPU path's own error must not be able to excuse anything).
             # Measured on this network over all 256 000 frames (profiles/r02_logit_error_vs_f64.json): fp32 CPU path 6.4e-4, default mode
             # 5.7e-4, exact-f32 mode 1.5e-3 against the float64 truth.
             assert st["max"] < (1.0e-3 if mode == "f16p" else 3.0e-3), (mode, "absolute max vs f64", st["max"])
-            assert st["rms"] < 2.0e-5, (mode, "absolute rms vs f64", st["rms"])
+            assert st["rms"] < (2.0e-5 if mode != "f16p3" else 4.0e-5), (mode, "absolute rms vs f64", st["rms"])
             assert st["frames_over_bound"] <= tail * max(st_cpu["frames_over_bound"], 1)
     rt.set_gemm_mode("f16p")
+    rt.set_recurrent_tile(0)
 
 
 @pytest.mark.parametrize("F,lstm,B,T", [(64, None, 256, 1000),                       # cfg 2: K = 64 and K = 256, N = 1024

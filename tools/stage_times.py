@@ -9,7 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--lib", default=None)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--reps", type=int, default=10)
-ap.add_argument("--mode", default="f16p", choices=["f16p", "f16p_stream", "f32"])
+ap.add_argument("--mode", default="f16p", choices=["f16p", "f16p_stream", "f32", "f16p3"])
 ap.add_argument("--tile", type=int, default=0, help="recurrent form: 0 = by estimated time, 4, 16")
 args = ap.parse_args()
 import uvad_amd

@@ -85,7 +85,9 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {
 }
 
 // NKB: 16-deep k-blocks of the contraction (K = 16 * NKB)
-template <int NKB>
+// NPROD: MFMA products per f32-equivalent product: 4 = the numerics above (weights exact); 3 = without P2 x a_hi (weights rounded to
+// 22 bits, the P2 fragments are not loaded: 64 registers fewer at K = 256): uvad_set_gemm_mode(3)
+template <int NKB, int NPROD>
 __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt, int nt, unsigned *counters) {
     constexpr int NST = Ring<NKB>::NST;
     static_assert(NKB % 2 == 0 && NKB % NST == 0 && NST - 1 <= NKB && NST >= 4, "ring / fragment double-buffer geometry");
@@ -115,7 +117,8 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
     if (c_cur >= my_tiles) return;   // nothing left for this workgroup (no DMA issued yet)
 
     // ---- the wave's W fragments for the whole K: lane (fr, fh) holds W[n_tile * 128 + wave * 32 + fr][16 kb + 8 fh .. + 8] of each plane
-    f16x8 w0[NKB], w1[NKB], w2[NKB];
+    static_assert(NPROD == 3 || NPROD == 4, "three or four products");
+    f16x8 w0[NKB], w1[NKB], w2[NPROD == 4 ? NKB : 1];
     {
         const size_t wplane = (size_t)((a.N + 127) / 128) * NKB * SLAB;
         const unsigned short *wb = a.Wsplit16 + (size_t)n_tile * NKB * SLAB + (wave * 32 + fr) * 16 + fh * 8;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
         for (int kb = 0; kb < NKB; ++kb) {
             w0[kb] = *reinterpret_cast<const f16x8 *>(wb + (size_t)kb * SLAB);
             w1[kb] = *reinterpret_cast<const f16x8 *>(wb + wplane + (size_t)kb * SLAB);
-            w2[kb] = *reinterpret_cast<const f16x8 *>(wb + 2 * wplane + (size_t)kb * SLAB);
+            if constexpr (NPROD == 4) w2[kb] = *reinterpret_cast<const f16x8 *>(wb + 2 * wplane + (size_t)kb * SLAB);
         }
     }
     // Transposed MFMA blocks (see (4)): accumulator register 4 q + j of lane (fr, fh) = row fr of the row block, column 8 q + 4 fh + j of
@@ -197,7 +200,10 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
         constexpr bool FIRST = decltype(first_tag)::value;
         // the weight fragments live in AGPRs (the MFMAs read them in place) and nothing else does: constraint only, no instruction
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+a"(w0[kb]), "+a"(w1[kb]), "+a"(w2[kb]));
+        for (int kb = 0; kb < NKB; ++kb) {
+            asm volatile("" : "+a"(w0[kb]), "+a"(w1[kb]));
+            if constexpr (NPROD == 4) asm volatile("" : "+a"(w2[kb]));
+        }
         const int c_n = clampc(c_nxt, c_cur);
         float *gout = a.C + ((size_t)(grp + GROUPS * c_cur) * n64 + g_ntile) * (128 * 64) + g_lane;
         unsigned pulled = 0;
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
                 if constexpr (p == 0) hi[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kb], ah[s][i], kb == 0 ? zero : hi[i], 0, 0, 0);
                 if constexpr (p == 1) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kb], ah[s][i], kb == 0 ? zero : lo[i], 0, 0, 0);
                 if constexpr (p == 2) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kb], al[s][i], lo[i], 0, 0, 0);
-                if constexpr (p == 3) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[kb], ah[s][i], lo[i], 0, 0, 0);
+                if constexpr (p == 3 && NPROD == 4) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2[kb], ah[s][i], lo[i], 0, 0, 0);   // (NPROD == 3: these slots of the stream stay empty)
             };
             // (hi + lo * 2^-11) * 2^-S + bias into the wave's staging image, four ds_write_b128 per row block.  (The image's previous
             // content was read during k-blocks 0 .. NKB - 2 of this tile: one wave's LDS operations execute in order.)
@@ -360,13 +366,19 @@ hipError_t launch_gemm_f16p_ws(const GemmArgs &a, unsigned *counters, int n_cu, 
     const int per = GROUPS * nt;
     int grid = (n_cu > 0 ? n_cu : 256) / per * per;
     if (grid < per) grid = per;
+    if (a.products != 0 && a.products != 3 && a.products != 4) return hipErrorInvalidValue;
+    const bool three = a.products == 3;
+#define UVAD_WS_LAUNCH(NKB_)                                                                                                          \
+    if (three) hipLaunchKernelGGL((gemm_f16p_ws_kernel<NKB_, 3>), dim3(grid), dim3(256), 0, s, a, mt, nt, counters);                   \
+    else hipLaunchKernelGGL((gemm_f16p_ws_kernel<NKB_, 4>), dim3(grid), dim3(256), 0, s, a, mt, nt, counters);
     switch (a.K / 16) {
-        case 4: hipLaunchKernelGGL((gemm_f16p_ws_kernel<4>), dim3(grid), dim3(256), 0, s, a, mt, nt, counters); break;
-        case 6: hipLaunchKernelGGL((gemm_f16p_ws_kernel<6>), dim3(grid), dim3(256), 0, s, a, mt, nt, counters); break;
-        case 8: hipLaunchKernelGGL((gemm_f16p_ws_kernel<8>), dim3(grid), dim3(256), 0, s, a, mt, nt, counters); break;
-        case 16: hipLaunchKernelGGL((gemm_f16p_ws_kernel<16>), dim3(grid), dim3(256), 0, s, a, mt, nt, counters); break;
+        case 4: UVAD_WS_LAUNCH(4) break;
+        case 6: UVAD_WS_LAUNCH(6) break;
+        case 8: UVAD_WS_LAUNCH(8) break;
+        case 16: UVAD_WS_LAUNCH(16) break;
         default: return hipErrorInvalidValue;
     }
+#undef UVAD_WS_LAUNCH
     return hipGetLastError();
 }
 

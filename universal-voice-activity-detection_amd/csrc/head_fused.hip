@@ -57,7 +57,7 @@ template <int N> __device__ __forceinline__ void hf_wait_vm_lgkm0() {   // s_wai
 }
 
 // NKS: pipeline steps of layer 1 (K1 = 32 * NKS)
-template <int NKS>
+template <int NKS, int NPROD>   // NPROD: 4 = all four products (weights exact), 3 = without the P2 planes (GemmArgs::products)
 __global__ __launch_bounds__(256, 1) void head_fused_kernel(HeadArgs a, int mt) {
     constexpr int NKB1 = 2 * NKS, NKB2 = LH / 16;
     static_assert(NKS % HNST == 0 || HNST % NKS == 0, "the stage of a step must not depend on the tile");
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void head_fused_kernel(HeadArgs a, int mt) 
     if (c_cur >= mt) return;
 
     // ---- weight fragments: lane (fr, fh) holds W[32 wave + fr][16 kb + 8 fh .. + 8] of each of the three planes
-    f16x8 w1a[NKB1], w1b[NKB1], w1c[NKB1], w2a[NKB2], w2b[NKB2], w2c[NKB2];
+    f16x8 w1a[NKB1], w1b[NKB1], w1c[NPROD == 4 ? NKB1 : 1], w2a[NKB2], w2b[NKB2], w2c[NPROD == 4 ? NKB2 : 1];
     {
         const size_t p1 = (size_t)NKB1 * (128 * 16), p2 = (size_t)NKB2 * (128 * 16);   // plane sizes (N = 128: one 128-row tile)
         const unsigned short *b1 = a.W1 + (wave * 32 + fr) * 16 + fh * 8, *b2 = a.W2 + (wave * 32 + fr) * 16 + fh * 8;
@@ -91,13 +91,13 @@ __global__ __launch_bounds__(256, 1) void head_fused_kernel(HeadArgs a, int mt) 
         for (int kb = 0; kb < NKB1; ++kb) {
             w1a[kb] = *reinterpret_cast<const f16x8 *>(b1 + (size_t)kb * 2048);
             w1b[kb] = *reinterpret_cast<const f16x8 *>(b1 + p1 + (size_t)kb * 2048);
-            w1c[kb] = *reinterpret_cast<const f16x8 *>(b1 + 2 * p1 + (size_t)kb * 2048);
+            if constexpr (NPROD == 4) w1c[kb] = *reinterpret_cast<const f16x8 *>(b1 + 2 * p1 + (size_t)kb * 2048);
         }
 #pragma unroll
         for (int kb = 0; kb < NKB2; ++kb) {
             w2a[kb] = *reinterpret_cast<const f16x8 *>(b2 + (size_t)kb * 2048);
             w2b[kb] = *reinterpret_cast<const f16x8 *>(b2 + p2 + (size_t)kb * 2048);
-            w2c[kb] = *reinterpret_cast<const f16x8 *>(b2 + 2 * p2 + (size_t)kb * 2048);
+            if constexpr (NPROD == 4) w2c[kb] = *reinterpret_cast<const f16x8 *>(b2 + 2 * p2 + (size_t)kb * 2048);
         }
     }
     // per accumulator register r (column 8 (r >> 2) + 4 fh + (r & 3) of the wave's 32): biases and the classifier weight
@@ -159,7 +159,10 @@ __global__ __launch_bounds__(256, 1) void head_fused_kernel(HeadArgs a, int mt) 
 
     auto tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int kb = 0; kb < NKB1; ++kb) asm volatile("" : "+a"(w1a[kb]), "+a"(w1b[kb]), "+a"(w1c[kb]));
+        for (int kb = 0; kb < NKB1; ++kb) {
+            asm volatile("" : "+a"(w1a[kb]), "+a"(w1b[kb]));
+            if constexpr (NPROD == 4) asm volatile("" : "+a"(w1c[kb]));
+        }
         const int c_n = clampc(c_nxt, c_cur);
         unsigned pulled = 0;
         // ================= layer 1: NKS steps of two k-blocks =================
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void head_fused_kernel(HeadArgs a, int mt) 
                 if constexpr (p == 0) hi[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1a[kb], ah[s][kk][i], first ? zero : hi[i], 0, 0, 0);
                 if constexpr (p == 1) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1b[kb], ah[s][kk][i], first ? zero : lo[i], 0, 0, 0);
                 if constexpr (p == 2) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1a[kb], al[s][kk][i], lo[i], 0, 0, 0);
-                if constexpr (p == 3) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1c[kb], ah[s][kk][i], lo[i], 0, 0, 0);
+                if constexpr (p == 3 && NPROD == 4) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1c[kb], ah[s][kk][i], lo[i], 0, 0, 0);
             };
 #define HF_M(j) M(std::integral_constant<int, (j)>{})
             constexpr int fb = stn * (HSTEP * 2);
@@ -264,8 +267,10 @@ __global__ __launch_bounds__(256, 1) void head_fused_kernel(HeadArgs a, int mt) 
                 for (int i = 0; i < 2; ++i) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2b[kb], zh[s][i], kb == 0 ? zero : lo[i], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2a[kb], zl[s][i], lo[i], 0, 0, 0);
+                if constexpr (NPROD == 4) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2c[kb], zh[s][i], lo[i], 0, 0, 0);
+                    for (int i = 0; i < 2; ++i) lo[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2c[kb], zh[s][i], lo[i], 0, 0, 0);
+                }
             });
         }
         HF_SB;
@@ -325,8 +330,12 @@ hipError_t launch_head_fused(const HeadArgs &a, int n_cu, hipStream_t s) {
     const int mt = (int)((a.M + TM - 1) / TM);
     const int ncu = n_cu > 0 ? n_cu : 256;
     const int grid = mt < ncu ? mt : ncu;
-    if (a.K1 == 256) hipLaunchKernelGGL((head_fused_kernel<8>), dim3(grid), dim3(256), 0, s, a, mt);
-    else if (a.K1 == 128) hipLaunchKernelGGL((head_fused_kernel<4>), dim3(grid), dim3(256), 0, s, a, mt);
+    if (a.products != 0 && a.products != 3 && a.products != 4) return hipErrorInvalidValue;
+    const bool three = a.products == 3;
+    if (a.K1 == 256 && three) hipLaunchKernelGGL((head_fused_kernel<8, 3>), dim3(grid), dim3(256), 0, s, a, mt);
+    else if (a.K1 == 256) hipLaunchKernelGGL((head_fused_kernel<8, 4>), dim3(grid), dim3(256), 0, s, a, mt);
+    else if (a.K1 == 128 && three) hipLaunchKernelGGL((head_fused_kernel<4, 3>), dim3(grid), dim3(256), 0, s, a, mt);
+    else if (a.K1 == 128) hipLaunchKernelGGL((head_fused_kernel<4, 4>), dim3(grid), dim3(256), 0, s, a, mt);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

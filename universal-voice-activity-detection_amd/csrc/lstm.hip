@@ -273,11 +273,12 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 
-template <bool PLANES>
+// NPROD = 3: without the P2 x h1 product (LstmArgs::products): no P2 image in LDS (17 KiB instead of 145), 48 MFMAs per wave and step
+template <bool PLANES, int NPROD>
 __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
     constexpr int H = 128, RB = 4, KST = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned short sm16[];
-    unsigned short *p2 = sm16, *hb = sm16 + R16_P2_ELEMS;
+    unsigned short *p2 = sm16, *hb = sm16 + (NPROD == 4 ? R16_P2_ELEMS : 0);
 
     const int tile16 = blockIdx.x, dir = blockIdx.y;
     const bool reverse = dir == 1;
@@ -296,7 +297,8 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(a.Whh16h_p2 + (size_t)dir * R16_P2_ELEMS);
         uint4 *dst = reinterpret_cast<uint4 *>(p2);
-        for (int i = threadIdx.x; i < R16_P2_ELEMS / 8; i += 512) dst[i] = src[i];
+        if constexpr (NPROD == 4)
+            for (int i = threadIdx.x; i < R16_P2_ELEMS / 8; i += 512) dst[i] = src[i];
         for (int i = threadIdx.x; i < R16_HB_ELEMS / 2; i += 512) reinterpret_cast<unsigned *>(hb)[i] = 0u;
     }
     // this lane's sequence: tile (of 4) and row offset; lanes of missing tiles in the last workgroup are clamped
@@ -389,7 +391,8 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
         // groups of rb + 1 behind sched_barriers measured 10 % slower, a forced [4 MFMA, 1 LDS read] cadence 3 % slower.
         float hnew[RB];
         f32x4 gpre[RB];
-        f16x8 w2n = *reinterpret_cast<const f16x8 *>(p2w);
+        f16x8 w2n = {};
+        if constexpr (NPROD == 4) w2n = *reinterpret_cast<const f16x8 *>(p2w);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             f32x4 hi = {0.f, 0.f, 0.f, 0.f}, lo = {0.f, 0.f, 0.f, 0.f};
@@ -397,13 +400,14 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
             for (int ks = 0; ks < KST; ++ks) {
                 const int f = rb * 4 + ks;
                 const f16x8 w2 = w2n;
-                if (f + 1 < 16) w2n = *reinterpret_cast<const f16x8 *>(p2w + (f + 1) * 512);
+                if constexpr (NPROD == 4)
+                    if (f + 1 < 16) w2n = *reinterpret_cast<const f16x8 *>(p2w + (f + 1) * 512);
                 const f16x8 w0 = __builtin_bit_cast(f16x8, w[f]);
                 const f16x8 w1 = __builtin_bit_cast(f16x8, w[16 + f]);
                 lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, h1[ks], lo, 0, 0, 0);
                 hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, h1[ks], hi, 0, 0, 0);
                 lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, h2[ks], lo, 0, 0, 0);
-                lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, h1[ks], lo, 0, 0, 0);
+                if constexpr (NPROD == 4) lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, h1[ks], lo, 0, 0, 0);
             }
             gpre[rb] = __builtin_elementwise_fma(__builtin_elementwise_fma(lo, f32x4{0.00048828125f, 0.00048828125f, 0.00048828125f, 0.00048828125f}, hi),
                                                  f32x4{wscale, wscale, wscale, wscale}, gq[rb]);
@@ -527,15 +531,20 @@ hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
     if (can16 && pick == 16) {
         if (tile_used) *tile_used = 16;
         const dim3 grid16((a.tiles + 3) / 4, a.dirs);
-        const size_t lds = (size_t)(R16_P2_ELEMS + R16_HB_ELEMS) * sizeof(unsigned short);   // 145 KiB: one workgroup per CU
+        if (a.products != 0 && a.products != 3 && a.products != 4) return hipErrorInvalidValue;
+        const bool three = a.products == 3;
+        const size_t lds = (size_t)((three ? 0 : R16_P2_ELEMS) + R16_HB_ELEMS) * sizeof(unsigned short);   // 145 KiB (17 without the P2 image): one workgroup per CU (registers)
+        const void *fn = planes ? (three ? reinterpret_cast<const void *>(lstm_rec16h_kernel<true, 3>) : reinterpret_cast<const void *>(lstm_rec16h_kernel<true, 4>))
+                                : (three ? reinterpret_cast<const void *>(lstm_rec16h_kernel<false, 3>) : reinterpret_cast<const void *>(lstm_rec16h_kernel<false, 4>));
         {   // the attribute belongs to the (function, device) pair and a process may own contexts on several GPUs (include/uvad.h), so it
             // is set for the CURRENT device on every launch (as launch_fbank / launch_sinc_conv do; no process-global "done" flag)
-            const void *fn = planes ? reinterpret_cast<const void *>(lstm_rec16h_kernel<true>) : reinterpret_cast<const void *>(lstm_rec16h_kernel<false>);
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        if (planes) hipLaunchKernelGGL((lstm_rec16h_kernel<true>), grid16, dim3(512), lds, s, a);
-        else hipLaunchKernelGGL((lstm_rec16h_kernel<false>), grid16, dim3(512), lds, s, a);
+        if (planes && three) hipLaunchKernelGGL((lstm_rec16h_kernel<true, 3>), grid16, dim3(512), lds, s, a);
+        else if (planes) hipLaunchKernelGGL((lstm_rec16h_kernel<true, 4>), grid16, dim3(512), lds, s, a);
+        else if (three) hipLaunchKernelGGL((lstm_rec16h_kernel<false, 3>), grid16, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((lstm_rec16h_kernel<false, 4>), grid16, dim3(512), lds, s, a);
         return hipGetLastError();
     }
     if (tile_used) *tile_used = 4;

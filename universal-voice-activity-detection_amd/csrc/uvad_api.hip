@@ -598,7 +598,12 @@ int uvad_fbank_i16(uvad_ctx *c, const int16_t *d_pcm, int B, int64_t S, float *d
 }
 
 // The feed-forward layers one GEMM each (leaky_relu epilogue): workspace buffers Y[last] -> Z[0] -> Z[1] ...; the last one f32.
-static bool mode_fuses_head(const uvad_ctx *c) { return c->gemm_mode == 1; }   // mode 2 keeps the per-layer kernels (A/B, reference of the tests)
+// modes 1 and 3 use the weight-stationary projection and the fused head for large launches; mode 2 keeps the tile-streaming / per-layer
+// kernels everywhere (A/B, reference of the tests); mode 3 = mode 1 with three MFMA products per f32-equivalent product in those
+// large-launch kernels and in the 16-sequence recurrence (weights rounded to 22 bits: GemmArgs::products)
+static bool mode_is_ws(const uvad_ctx *c) { return c->gemm_mode == 1 || c->gemm_mode == 3; }
+static bool mode_fuses_head(const uvad_ctx *c) { return mode_is_ws(c); }
+static int mode_products(const uvad_ctx *c) { return c->gemm_mode == 3 ? 3 : 4; }
 static int feed_forward_layers(uvad_ctx *c, const WsLayout &w, char *base, int B, int T, bool f16, hipStream_t s) {
     const uvad_model_cfg &m = c->mc;
     auto Yf = [&](int i) { return reinterpret_cast<float *>(base + w.off_Y[i]); };
@@ -670,7 +675,8 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
             } else {
                 g.Ah = hi_of(w.off_Y[(k - 1) & 1]); g.Al = lo_of(w.off_Y[(k - 1) & 1], w.Wd); g.lda = w.Wd; g.K = w.Wd;
             }
-            if (c->gemm_mode == 1 && gemm_f16p_ws_supported(g, c->n_cu))   // large launches: weights stay in registers, bit-identical gates
+            g.products = mode_products(c);
+            if (mode_is_ws(c) && gemm_f16p_ws_supported(g, c->n_cu))   // large launches: weights stay in registers, bit-identical gates
                 HIPCHK(c, launch_gemm_f16p_ws(g, reinterpret_cast<unsigned *>(base + w.off_ctr), c->n_cu, s));
             else
                 HIPCHK(c, launch_gemm_f16p(g, s));
@@ -691,6 +697,7 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         if (y_planes(k)) { r.Yh = hi_of(w.off_Y[k & 1]); r.Yl = lo_of(w.off_Y[k & 1], w.Wd); }
         else r.Y = Yf(k & 1);
         r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D; r.tile_mode = ss ? 4 : c->rec_tile_mode; r.n_cu = c->n_cu;
+        r.products = f16 ? mode_products(c) : 4;
         if (ss) {   // carried (h, c) of this layer, updated in place
             r.h0 = r.hN = ss->h + (size_t)k * ss->layer_stride;
             r.c0 = r.cN = ss->c + (size_t)k * ss->layer_stride;
@@ -710,6 +717,7 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         h.b1 = c->lin_b[0]; h.b2 = c->lin_b[1]; h.wc = c->cls_w; h.bc = c->cls_b; h.slope = m.leaky_slope;
         h.logits = d_logits; h.probs = d_probs; h.tiles = w.tiles; h.T = T; h.B = B; h.ld_out = ld_out > 0 ? ld_out : T;
         h.counter = reinterpret_cast<unsigned *>(base + w.off_ctr);
+        h.products = mode_products(c);
         HIPCHK(c, launch_head_fused(h, c->n_cu, s));
         if (c->timing) {
             HIPCHK(c, hipEventRecord(c->ev[3], s));
@@ -972,7 +980,8 @@ int uvad_label_runs(uvad_ctx *c, const uint8_t *d_labels, int B, int T, int max_
 
 int uvad_set_gemm_mode(uvad_ctx *c, int mode) {
     if (!c) return UVAD_E_ARG;
-    if (mode < 0 || mode > 2) return fail(c, UVAD_E_ARG, "gemm mode must be 0 (exact f32 MFMA), 1 (split-f16 x3) or 2 (split-f16 x3, tile-streaming kernel only)");
+    if (mode < 0 || mode > 3)
+        return fail(c, UVAD_E_ARG, "gemm mode must be 0 (exact f32 MFMA), 1 (split f16, 4 products), 2 (the same, tile-streaming kernels only) or 3 (split f16, 3 products)");
     c->gemm_mode = mode;
     return UVAD_OK;
 }

@@ -46,6 +46,7 @@ struct GemmArgs {
     float wscale;                     // 2^-S
     unsigned short *Ch, *Cl;          // out_planes: K-blocked f16 planes of the result, ldc columns ([N, ldc) written as zero)
     int out_planes;
+    int products;        // gemm_f16p_ws.hip: 4 (0 reads as 4) = all four products above, weights exact; 3 = without P2 x a_hi (weights rounded to 22 bits)
     // ---- common
     int c_blocked;       // C is the tile-blocked gate matrix (g_index, ncols = N) instead of row-major [M][ldc]
     int ldw;
@@ -93,6 +94,7 @@ struct LstmArgs {
     const unsigned *Whh16h_regs; const unsigned short *Whh16h_p2; const float *whh16h_scale;
     float *Y; int ldy;           // f32 output (exact-f32 GEMM mode), or
     unsigned short *Yh, *Yl;     // the two K-blocked f16 planes (ldy columns) h ~= hi + lo * 2^-11 the f16p GEMM of the next layer reads (Y == nullptr)
+    int products;                // 16-sequence form: 4 (0 reads as 4) or 3 (no P2 plane: see GemmArgs)
     int tiles, T, H, dirs;
     int tile_mode;               // sequences per workgroup: 0 = by estimated time, 4, 16 (see launch_lstm)
     int n_cu;                    // compute units of the device (0 = 256)
@@ -143,6 +145,7 @@ struct HeadArgs {
     float *logits, *probs;           // canonical [b][t] (b < B only), row stride ld_out; either may be nullptr
     int tiles, T, B, ld_out;
     unsigned *counter;               // one word of device memory (zeroed by the launcher)
+    int products;                    // 4 (0 reads as 4) or 3 (no P2 plane: see GemmArgs)
 };
 bool head_fused_supported(int K1, int lin_hidden, int lin_layers, long long M, int n_cu);
 hipError_t launch_head_fused(const HeadArgs &a, int n_cu, hipStream_t s);

@@ -307,8 +307,9 @@ class VadRuntime:
     def set_gemm_mode(self, mode: str):
         """"f32": exact f32 MFMA; "f16p": split-f16 on the f16 matrix cores (default: the weight-stationary kernel for the large
         projections, the tile-streaming one elsewhere); "f16p_stream": split-f16 with the tile-streaming kernel only (same bits,
-        kept for A/B runs and as the reference of the bit-identity test)."""
-        self._check(self.lib.uvad_set_gemm_mode(self.ctx, {"f32": 0, "f16p": 1, "f16p_stream": 2}[mode]))
+        kept for A/B runs and as the reference of the bit-identity test); "f16p3": "f16p" with three instead of four MFMA products
+        per f32-equivalent product in the large-launch kernels (weights rounded to 22 bits; faster, see include/uvad.h)."""
+        self._check(self.lib.uvad_set_gemm_mode(self.ctx, {"f32": 0, "f16p": 1, "f16p_stream": 2, "f16p3": 3}[mode]))
 
     def set_recurrent_tile(self, sequences: int):
         """Sequences per recurrent workgroup: 0 (default) = chosen from the batch size, 4 = latency form, 16 = throughput form."""
