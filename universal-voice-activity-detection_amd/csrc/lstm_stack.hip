@@ -1,0 +1,213 @@
+// lstm_stack.hip -- the whole LSTM stack of a CAUSAL model for a few new frames, one launch (uvad_stream_step, BASELINE cfg 5).
+// Reference: the same `self.lstm(outputs)` of PyanNet2.forward (src/models/segmentation/PyanNet2.py:169-172) with
+// bidirectional=False, called chunk after chunk with the (h, c) of every layer carried -- what a real-time feed does.
+//
+// Why.  A streaming step of 512 feeds x 20 ms is 2 frames per feed: as per-layer kernels it was 8 dependent launches (projection +
+// recurrence per layer) of a few microseconds of work each, and the step's latency was the launches (0.104 ms for 11 of them).
+// In a causal stack nothing couples two sequences: layer l + 1 of a sequence needs layer l of THAT sequence only.  So one
+// workgroup takes 4 sequences through ALL layers for the step's T <= 8 frames and no workgroup ever waits for another:
+//   per layer   phase A: W_ih's register image -> the wave's 128 resident registers (the A operand of v_mfma_f32_4x4x1_16B_f32, as
+//                        in lstm_rec_kernel); gates_t = b + W_ih x_t for the T frames, x_t read from LDS (the features, then the
+//                        previous layer's h_t); a lane ends a chain holding the four gate pre-activations of ONE (unit, sequence)
+//                        pair, kept in registers;
+//               phase B: W_hh's image into the same registers; T recurrence steps exactly as lstm_rec_kernel's (h through a
+//                        double-buffered LDS tile, one barrier per step), h_t also written where the next layer reads its input.
+// Exact f32 throughout (the MFMA is a k-ordered fmaf chain); the weights (about 2 MB per workgroup at 4 x 128 units) come from L2.
+// The last layer's h_t leaves as the two K-blocked f16 planes the fused head reads (or f32 rows).
+#include "uvad_internal.h"
+
+namespace uvad {
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr float L2E = 1.4426950408889634f;
+
+// gate functions: the ones of lstm.hip (held to ~1 ulp of absolute error at their output scale)
+__device__ __forceinline__ float rcp_nr(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float sigmoid_f(float x) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_fminf(-L2E * x, 126.0f));
+    return rcp_nr(1.0f + e);
+}
+__device__ __forceinline__ float tanh_f(float x) {
+    const float e = __builtin_amdgcn_exp2f((-2.0f * L2E) * __builtin_fabsf(x));
+    const float n = 1.0f - e, d = 1.0f + e;
+    const float r = __builtin_amdgcn_rcpf(d);
+    float q = n * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+    return __builtin_copysignf(q, x);
+}
+__device__ __forceinline__ float lstm_cell(const f32x4 g, float &c) {
+    const float ig = sigmoid_f(g[0]), fg = sigmoid_f(g[1]), gg = tanh_f(g[2]), og = sigmoid_f(g[3]);
+    c = __builtin_fmaf(fg, c, ig * gg);
+    return og * tanh_f(c);
+}
+
+constexpr int H = 128, WAVES = 8, HS = H + 4;   // LDS row stride (floats): the 4 sequence rows land on disjoint banks
+
+// init + sum_k w[k] * v[k] over 4 KQ values of the lane's sequence row `vrow` (LDS): four independent chains (k mod 4), HR LDS reads in flight
+// HR: LDS reads kept in flight ahead of the MFMA groups (lstm_rec_kernel keeps 8; here gq[] needs the registers: 4, or 2 where 4 would spill)
+template <int KQ, int HR>
+__device__ __forceinline__ f32x4 chain(float (&w)[H], const float *vrow, f32x4 init) {
+    static_assert(KQ >= HR, "ring depth");
+#pragma unroll
+    for (int k = 0; k < 4 * KQ; ++k) asm volatile("" : "+a"(w[k]));   // resident in the accumulator half of the register file (constraint only)
+    float4 hv[HR];
+#pragma unroll
+    for (int kq = 0; kq < HR; ++kq) hv[kq] = *reinterpret_cast<const float4 *>(vrow + 4 * kq);
+    f32x4 a0 = init, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f}, a3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+        const float4 hq = hv[kq % HR];
+        if (kq + HR < KQ) hv[kq % HR] = *reinterpret_cast<const float4 *>(vrow + 4 * (kq + HR));
+        a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * kq + 0], hq.x, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * kq + 1], hq.y, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * kq + 2], hq.z, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(w[4 * kq + 3], hq.w, a3, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, HR, 0);
+#pragma unroll
+    for (int i = 0; i < KQ - HR; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * HR, 0);
+    return (a0 + a1) + (a2 + a3);
+}
+
+template <int KQ>
+__device__ __forceinline__ void load_image(float (&w)[H], const float *img, int wave, int lane) {
+    const float4 *wp = reinterpret_cast<const float4 *>(img);
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+        const float4 v = wp[(size_t)(wave * KQ + kq) * 64 + lane];
+        w[4 * kq + 0] = v.x; w[4 * kq + 1] = v.y; w[4 * kq + 2] = v.z; w[4 * kq + 3] = v.w;
+    }
+}
+
+// KIN0: feature width (columns of layer 0's W_ih): 64 or 80 (other widths: the per-layer kernels)
+template <int KIN0, bool PLANES>
+__global__ __launch_bounds__(WAVES * 64) void lstm_stack_kernel(LstmStackArgs a) {
+    constexpr int TMAX = LSTM_STACK_TMAX;
+    constexpr int HR = KIN0 == 64 ? 4 : 2;
+    __shared__ __attribute__((aligned(16))) float xbuf[TMAX][SEQ_TILE][HS];   // input of the current layer, frame by frame
+    __shared__ __attribute__((aligned(16))) float hbuf[2][SEQ_TILE][HS];
+
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jb = lane & 3;    // sequence within the tile (B / D operand column), gate index of the A operand
+    const int blk = lane >> 2;  // MFMA block = hidden unit within the wave's row block
+    const int unit = wave * 16 + blk;
+    const int T = a.T;
+
+    // ---- the features of the tile's 4 sequences (canonical [B][T][KIN0]; rows of padding sequences read as zero)
+    for (int i = tid; i < T * SEQ_TILE * (KIN0 / 4); i += WAVES * 64) {
+        const int q = i % (KIN0 / 4), j = (i / (KIN0 / 4)) % SEQ_TILE, t = i / (KIN0 / 4 * SEQ_TILE);
+        const int b = tile * SEQ_TILE + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < a.B) v = *reinterpret_cast<const float4 *>(a.feats + ((size_t)b * T + t) * KIN0 + 4 * q);
+        *reinterpret_cast<float4 *>(&xbuf[t][j][4 * q]) = v;
+    }
+
+    // (32-bit offsets: a step's outputs and a layer's state are far below 2^31 elements; launch_lstm_stack checks)
+    const unsigned so = (unsigned)((tile * SEQ_TILE + jb) * H + unit);   // this lane's (sequence, unit) in a layer's state
+    const unsigned rowu = (unsigned)(tile * T * SEQ_TILE);               // row of (t, jb) in the tile-major outputs = rowu + 4 t + jb
+    const unsigned y_wave = (unsigned)(wave * (PLANE_TILE * 16));
+    const unsigned y_lane = (unsigned)(jb * 16 + blk);
+    const unsigned y_tile = (unsigned)((a.ldy / 16) * (PLANE_TILE * 16));
+
+    float w[H];
+    for (int l = 0; l < a.n_layers; ++l) {
+        const bool last = l + 1 == a.n_layers;
+        // ---- phase A: gate pre-activations of the T frames from the layer's input
+        const float4 b4 = *reinterpret_cast<const float4 *>(a.bias[l] + unit * 4);
+        const f32x4 bias = {b4.x, b4.y, b4.z, b4.w};
+        f32x4 gq[TMAX];
+        if (l == 0) {
+            load_image<KIN0 / 4>(w, a.wih[0], wave, lane);
+            __syncthreads();   // the features are in LDS
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < T) gq[t] = chain<KIN0 / 4, HR>(w, &xbuf[t][jb][0], bias);
+        } else {
+            load_image<H / 4>(w, a.wih[l], wave, lane);
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < T) gq[t] = chain<H / 4, HR>(w, &xbuf[t][jb][0], bias);
+        }
+        // ---- phase B: the recurrence over the T frames, carried state in / out
+        load_image<H / 4>(w, a.whh[l], wave, lane);
+        const size_t lo = (size_t)l * a.layer_stride + so;   // (scalar part + the lane's 32-bit offset)
+        float c = a.c[lo];
+        float hlast = a.h[lo];
+        hbuf[0][jb][unit] = hlast;
+        __syncthreads();   // every wave has read its input frames (xbuf is rewritten below) and hbuf[0] is complete
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            if (t < T) {
+                hlast = lstm_cell(chain<H / 4, HR>(w, &hbuf[t & 1][jb][0], gq[t]), c);
+                hbuf[(t + 1) & 1][jb][unit] = hlast;
+                if (!last) {
+                    xbuf[t][jb][unit] = hlast;             // the next layer's input
+                } else if constexpr (PLANES) {
+                    const unsigned R = rowu + (unsigned)t * SEQ_TILE;
+                    const unsigned yo = (R >> 7) * y_tile + y_wave + (R & 127) * 16 + y_lane;
+                    const _Float16 hh = (_Float16)hlast;
+                    a.Yh[yo] = __builtin_bit_cast(unsigned short, hh);
+                    a.Yl[yo] = __builtin_bit_cast(unsigned short, (_Float16)((hlast - (float)hh) * 2048.0f));
+                } else {
+                    a.Y[(size_t)(rowu + jb + (unsigned)t * SEQ_TILE) * a.ldy + unit] = hlast;
+                }
+                __syncthreads();
+            }
+        }
+        a.h[lo] = hlast;
+        a.c[lo] = c;
+    }
+}
+
+}  // namespace
+
+size_t lstm_image_elems(int K) { return (size_t)4 * H * K; }
+
+// register image of a [4H][K] torch matrix (rows i,f,g,o blocks of H) for lstm_stack_kernel / lstm_rec_kernel:
+// [wave][kq = k/4][lane 64][4 k] with lane = (unit within the wave) * 4 + gate
+void pack_lstm_image(const float *wm, int K, float *out) {
+    for (int wave = 0; wave < WAVES; ++wave)
+        for (int kq = 0; kq < K / 4; ++kq)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int gate = lane & 3, unit = wave * 16 + (lane >> 2);
+                    out[((size_t)(wave * (K / 4) + kq) * 64 + lane) * 4 + e] = wm[(size_t)(gate * H + unit) * K + 4 * kq + e];
+                }
+}
+
+bool lstm_stack_supported(int hidden, int dirs, int in_dim, int T, int n_layers) {
+    return hidden == H && dirs == 1 && (in_dim == 64 || in_dim == 80) && T >= 1 && T <= LSTM_STACK_TMAX && n_layers >= 1 &&
+           n_layers <= LSTM_STACK_MAX_LAYERS;
+}
+
+hipError_t launch_lstm_stack(const LstmStackArgs &a, hipStream_t s) {
+    if (a.tiles <= 0 || a.T <= 0) return hipSuccess;
+    if (!lstm_stack_supported(H, 1, a.kin0, a.T, a.n_layers) || !a.feats || !a.h || !a.c) return hipErrorInvalidValue;
+    if ((long long)a.tiles * SEQ_TILE * a.T * (a.ldy > H ? a.ldy : H) >= (1LL << 31)) return hipErrorInvalidValue;   // 32-bit offsets in the kernel
+    const bool planes = a.Y == nullptr;
+    if (planes && (!a.Yh || !a.Yl)) return hipErrorInvalidValue;
+    const dim3 grid(a.tiles), block(WAVES * 64);
+#define UVAD_STACK_LAUNCH(K_)                                                                  \
+    if (planes) hipLaunchKernelGGL((lstm_stack_kernel<K_, true>), grid, block, 0, s, a);      \
+    else hipLaunchKernelGGL((lstm_stack_kernel<K_, false>), grid, block, 0, s, a);
+    switch (a.kin0) {
+        case 64: UVAD_STACK_LAUNCH(64) break;
+        case 80: UVAD_STACK_LAUNCH(80) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef UVAD_STACK_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace uvad

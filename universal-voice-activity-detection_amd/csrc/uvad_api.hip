@@ -26,6 +26,7 @@ struct LayerDev {
     float w_ih_scale = 1.0f;
     float *bias = nullptr;   // [dirs*4H] b_ih + b_hh, same permutation
     float *w_hh = nullptr;   // [dirs][packed register image]
+    float *w_ih_img = nullptr;   // causal H = 128 models: W_ih as a register image (lstm_stack.hip), else nullptr
     unsigned *w_hh16_regs = nullptr;        // 16-sequence kernel (H = 128): [dirs][P0 / P1 register image]
     unsigned short *w_hh16_p2 = nullptr;    // [dirs][P2 LDS image]
     float *w_hh16_scale = nullptr;          // [dirs] 2^-S
@@ -341,6 +342,7 @@ int uvad_finalize(uvad_ctx *c) {
         std::vector<unsigned short> hh16p(H == 128 ? (size_t)D * whh16h_p2_elems() : 0, 0);
         std::vector<float> hh16s(D, 1.0f);
         bool hh16ok = H == 128;
+        std::vector<float> ih_img;
         for (int d = 0; d < D; ++d) {
             const std::string suf = "_l" + std::to_string(k) + (d ? "_reverse" : "");
             const HostTensor *wih = get("lstm.weight_ih" + suf), *whh = get("lstm.weight_hh" + suf);
@@ -357,6 +359,10 @@ int uvad_finalize(uvad_ctx *c) {
                     bp[dst] = bih->data[src] + bhh->data[src];
                 }
             pack_whh(whh->data.data(), H, &hh[(size_t)d * whh_packed_elems(H)]);
+            if (D == 1 && H == 128 && in % 4 == 0) {   // the streaming step's one-launch stack (lstm_stack.hip)
+                ih_img.resize(lstm_image_elems(in));
+                pack_lstm_image(wih->data.data(), in, ih_img.data());
+            }
             if (H == 128 && !pack_whh16h(whh->data.data(), &hh16r[(size_t)d * whh16h_regs_elems()], &hh16p[(size_t)d * whh16h_p2_elems()], &hh16s[d]))
                 hh16ok = false;
         }
@@ -371,6 +377,7 @@ int uvad_finalize(uvad_ctx *c) {
         }
         if ((r = dev_upload(c, bp.data(), bp.size(), &L.bias, true))) return r;
         if ((r = dev_upload(c, hh.data(), hh.size(), &L.w_hh, true))) return r;
+        if (!ih_img.empty() && (r = dev_upload(c, ih_img.data(), ih_img.size(), &L.w_ih_img, true))) return r;
         if (H == 128) {
             if ((r = dev_upload(c, hh16r.data(), hh16r.size(), &L.w_hh16_regs, true))) return r;
             if ((r = dev_upload(c, hh16p.data(), hh16p.size(), &L.w_hh16_p2, true))) return r;
@@ -634,6 +641,15 @@ static int feed_forward_layers(uvad_ctx *c, const WsLayout &w, char *base, int B
     return UVAD_OK;
 }
 
+// true if a streaming step of T new frames runs the LSTM stack as one launch (lstm_stack.hip)
+static bool stream_uses_stack(const uvad_ctx *c, int T) {
+    const uvad_model_cfg &m = c->mc;
+    if (!lstm_stack_supported(m.hidden, m.bidirectional ? 2 : 1, m.in_dim, T, m.num_layers)) return false;
+    for (int k = 0; k < m.num_layers; ++k)
+        if (!c->layers[k].w_ih_img) return false;
+    return true;
+}
+
 // check_range: the features come from the caller (or from a front end with learnable scales) and may lie outside the f16
 // range; the split-f16 layer-0 projection is then replaced by the exact-f32 one ON THE DEVICE (both are enqueued, a flag
 // written by range_flag_kernel lets exactly one of them run), so the call stays asynchronous and capturable.
@@ -659,7 +675,23 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
     auto y_planes = [&](int k) { return f16 && (k + 1 < m.num_layers || m.lin_layers > 0); };
     if (c->timing && record_start) HIPCHK(c, hipEventRecord(c->ev[0], s));
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
-    for (int k = 0; k < m.num_layers; ++k) {
+    // Streaming steps of a causal model: the whole stack in one launch (lstm_stack.hip; every layer of a sequence depends on that
+    // sequence only, so a workgroup takes its 4 sequences through all layers).  Needs the f32 features (uvad_stream_step asks the
+    // feature kernel for them when stream_uses_stack() says so).
+    const bool use_stack = ss && !feats_in_planes && stream_uses_stack(c, T);
+    if (use_stack) {
+        LstmStackArgs q{};
+        q.feats = d_feats; q.kin0 = m.in_dim; q.n_layers = m.num_layers;
+        for (int k = 0; k < m.num_layers; ++k) { q.wih[k] = c->layers[k].w_ih_img; q.whh[k] = c->layers[k].w_hh; q.bias[k] = c->layers[k].bias; }
+        q.h = ss->h; q.c = ss->c; q.layer_stride = ss->layer_stride;
+        const int lastl = m.num_layers - 1;
+        if (y_planes(lastl)) { q.Yh = hi_of(w.off_Y[lastl & 1]); q.Yl = lo_of(w.off_Y[lastl & 1], w.Wd); }
+        else q.Y = Yf(lastl & 1);
+        q.ldy = w.Wd; q.tiles = w.tiles; q.T = T; q.B = B;
+        HIPCHK(c, launch_lstm_stack(q, s));
+        c->rec_tile_used = 4;
+    }
+    for (int k = 0; k < (use_stack ? 0 : m.num_layers); ++k) {
         const LayerDev &L = c->layers[k];
         GemmArgs g{};
         g.W = L.w_ih; g.ldw = gemm_padded_k(L.in); g.Wsplit16 = L.w_ih_split16; g.wscale = L.w_ih_scale; g.bias = L.bias; g.C = G;
@@ -916,7 +948,8 @@ int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, vo
     fa.frame_len = L; fa.frame_shift = sh; fa.n_mels = c->fb.n_mels;
     fa.preemph = c->fb.preemph; fa.log_floor = c->fb.log_floor; fa.remove_dc = c->fb.remove_dc; fa.snip_edges = 1;
     fa.feats = feats;
-    const bool planes = c->gemm_mode >= 1 && c->f16_ok;   // as in uvad_forward: features straight into the first projection's operand planes
+    // as in uvad_forward: features straight into the first projection's operand planes -- unless the one-launch stack runs (f32 features)
+    const bool planes = c->gemm_mode >= 1 && c->f16_ok && !stream_uses_stack(c, k);
     if (planes) {
         fa.plane_hi = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(cws) + w.off_fplanes);
         fa.plane_lo = fa.plane_hi + plane_rows(w.M) * (size_t)w.Fp;

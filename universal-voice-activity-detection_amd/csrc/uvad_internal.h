@@ -112,6 +112,25 @@ size_t whh16h_regs_elems();
 size_t whh16h_p2_elems();
 bool pack_whh16h(const float *w_hh, unsigned *regs, unsigned short *p2, float *wscale);   // false: a weight is non-finite
 
+// ---- lstm_stack.hip: every layer of a causal (one-direction, H = 128) stack for T <= LSTM_STACK_TMAX new frames in ONE launch, carried
+//      (h, c) updated in place: the streaming step (uvad_stream_step).  Exact f32.
+constexpr int LSTM_STACK_TMAX = 4, LSTM_STACK_MAX_LAYERS = 8;
+struct LstmStackArgs {
+    const float *feats; int kin0;                 // canonical [B][T][kin0] f32 features
+    const float *wih[LSTM_STACK_MAX_LAYERS];      // register images of W_ih (pack_lstm_image, K = kin0 for layer 0, 128 after)
+    const float *whh[LSTM_STACK_MAX_LAYERS];      // register images of W_hh (pack_whh)
+    const float *bias[LSTM_STACK_MAX_LAYERS];     // [4H] b_ih + b_hh in (unit, gate) order
+    int n_layers;
+    float *h, *c; size_t layer_stride;            // carried state [layer][tiles * SEQ_TILE][128] (layer_stride floats apart)
+    float *Y; int ldy;                            // last layer's output: f32 rows (tile-major), or
+    unsigned short *Yh, *Yl;                      // its two K-blocked f16 planes of ldy columns (Y == nullptr)
+    int tiles, T, B;
+};
+bool lstm_stack_supported(int hidden, int dirs, int in_dim, int T, int n_layers);
+hipError_t launch_lstm_stack(const LstmStackArgs &a, hipStream_t s);
+size_t lstm_image_elems(int K);
+void pack_lstm_image(const float *w /*[4 * 128][K], torch row order*/, int K, float *out);
+
 // ---- head.hip -----------------------------------------------------------------------------
 // logit = Z[m][:K] . w + b ; prob = sigmoid(logit); written at canonical [b][t] (b < B only).
 struct ClsArgs {
