@@ -151,8 +151,8 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_stack_kernel(LstmStackArgs a)
             if (t < T) {
                 hlast = lstm_cell(chain<H / 4, HR>(w, &hbuf[t & 1][jb][0], gq[t]), c);
                 hbuf[(t + 1) & 1][jb][unit] = hlast;
-                if (!last) {
-                    xbuf[t][jb][unit] = hlast;             // the next layer's input
+                if (!last || a.logits) {
+                    xbuf[t][jb][unit] = hlast;             // the next layer's (or the head's) input
                 } else if constexpr (PLANES) {
                     const unsigned R = rowu + (unsigned)t * SEQ_TILE;
                     const unsigned yo = (R >> 7) * y_tile + y_wave + (R & 127) * 16 + y_lane;
@@ -168,11 +168,59 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_stack_kernel(LstmStackArgs a)
         a.h[lo] = hlast;
         a.c[lo] = c;
     }
+    if (!a.logits) return;
+
+    // ---- the head on the tile's T x 4 rows: feed-forward layers (reference: PyanNet2.py:183-185) with the SAME chain machinery -- a
+    //      128 x 128 matrix is 32 MFMA blocks of 4 output units, i.e. the row blocks of waves 0 and 1; a lane ends a chain holding 4
+    //      consecutive output units of (frame t, sequence jb) -- then the classifier row and the sigmoid (PyanNet2.py:186-187).
+    for (int j = 0; j < a.n_lin; ++j) {
+        f32x4 z[TMAX];
+        if (wave < 2) {
+            load_image<H / 4>(w, a.lin_w[j], wave, lane);
+            const float4 b4 = *reinterpret_cast<const float4 *>(a.lin_b[j] + unit * 4);
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < T) {
+                    z[t] = chain<H / 4, HR>(w, &xbuf[t][jb][0], f32x4{b4.x, b4.y, b4.z, b4.w});
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z[t][e] = z[t][e] >= 0.f ? z[t][e] : a.slope * z[t][e];
+                }
+        }
+        __syncthreads();   // every chain has read its input rows
+        if (wave < 2) {
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t)
+                if (t < T) *reinterpret_cast<float4 *>(&xbuf[t][jb][unit * 4]) = make_float4(z[t][0], z[t][1], z[t][2], z[t][3]);
+        }
+        __syncthreads();
+    }
+    if (tid < T * SEQ_TILE) {
+        const int t = tid / SEQ_TILE, j = tid % SEQ_TILE, b = tile * SEQ_TILE + j;
+        float acc = a.cls_b[0];
+        for (int k = 0; k < H; ++k) acc = __builtin_fmaf(a.cls_w[k], xbuf[t][j][k], acc);
+        if (b < a.B) {
+            a.logits[(size_t)b * a.ld_out + t] = acc;
+            if (a.probs) a.probs[(size_t)b * a.ld_out + t] = 1.0f / (1.0f + expf(-acc));
+        }
+    }
 }
 
 }  // namespace
 
 size_t lstm_image_elems(int K) { return (size_t)4 * H * K; }
+size_t fc_image_elems() { return (size_t)H * H; }
+
+// register image of a 128 x 128 nn.Linear weight for the head phase of lstm_stack_kernel: waves 0 and 1, MFMA block blk of wave w =
+// output units 4 (16 w + blk) .. + 3 (the A operand's four rows): [wave 2][kq = k/4][lane 64][4 k], lane = blk * 4 + row
+void pack_fc_image(const float *wm, float *out) {
+    for (int wave = 0; wave < 2; ++wave)
+        for (int kq = 0; kq < H / 4; ++kq)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int o = (wave * 16 + (lane >> 2)) * 4 + (lane & 3);
+                    out[((size_t)(wave * (H / 4) + kq) * 64 + lane) * 4 + e] = wm[(size_t)o * H + 4 * kq + e];
+                }
+}
 
 // register image of a [4H][K] torch matrix (rows i,f,g,o blocks of H) for lstm_stack_kernel / lstm_rec_kernel:
 // [wave][kq = k/4][lane 64][4 k] with lane = (unit within the wave) * 4 + gate
@@ -196,7 +244,8 @@ hipError_t launch_lstm_stack(const LstmStackArgs &a, hipStream_t s) {
     if (!lstm_stack_supported(H, 1, a.kin0, a.T, a.n_layers) || !a.feats || !a.h || !a.c) return hipErrorInvalidValue;
     if ((long long)a.tiles * SEQ_TILE * a.T * (a.ldy > H ? a.ldy : H) >= (1LL << 31)) return hipErrorInvalidValue;   // 32-bit offsets in the kernel
     const bool planes = a.Y == nullptr;
-    if (planes && (!a.Yh || !a.Yl)) return hipErrorInvalidValue;
+    if (!a.logits && planes && (!a.Yh || !a.Yl)) return hipErrorInvalidValue;
+    if (a.logits && (a.n_lin < 0 || a.n_lin > LSTM_STACK_MAX_LIN || !a.cls_w || !a.cls_b || a.ld_out < a.T)) return hipErrorInvalidValue;
     const dim3 grid(a.tiles), block(WAVES * 64);
 #define UVAD_STACK_LAUNCH(K_)                                                                  \
     if (planes) hipLaunchKernelGGL((lstm_stack_kernel<K_, true>), grid, block, 0, s, a);      \

@@ -52,6 +52,7 @@ struct uvad_ctx {
     std::vector<LayerDev> layers;
     std::vector<float *> lin_w, lin_b;
     std::vector<unsigned short *> lin_w_split16;
+    std::vector<float *> lin_w_img;   // 128 x 128 layers as register images (lstm_stack.hip), else nullptr
     std::vector<float> lin_w_scale;
     bool f16_ok = true;   // every GEMM operand the weights determine fits the f16 range (gemm mode 1 is usable)
     int gemm_mode = 1;    // 0: exact f32 MFMA (gemm.hip); 1: split-f16 x3 (gemm_f16p.hip)
@@ -388,6 +389,7 @@ int uvad_finalize(uvad_ctx *c) {
     c->lin_w.assign(m.lin_layers, nullptr);
     c->lin_b.assign(m.lin_layers, nullptr);
     c->lin_w_split16.assign(m.lin_layers, nullptr);
+    c->lin_w_img.assign(m.lin_layers, nullptr);
     c->lin_w_scale.assign(m.lin_layers, 1.0f);
     int prev = H * D;
     // Static bound on what the feed-forward GEMMs can be fed: |h| < 1 out of the LSTM, so |z_j| <= sum_k |w_jk| * amax + |b_j|
@@ -416,6 +418,11 @@ int uvad_finalize(uvad_ctx *c) {
             if ((r = dev_upload(c, sp.data(), sp.size(), &c->lin_w_split16[j], true))) return r;
         }
         if ((r = dev_upload(c, b->data.data(), b->data.size(), &c->lin_b[j], true))) return r;
+        if (m.lin_hidden == 128 && prev == 128) {   // the streaming step's in-launch head (lstm_stack.hip)
+            std::vector<float> img(fc_image_elems());
+            pack_fc_image(w->data.data(), img.data());
+            if ((r = dev_upload(c, img.data(), img.size(), &c->lin_w_img[j], true))) return r;
+        }
         amax = zmax * std::fmax(1.0, std::fabs((double)m.leaky_slope));
         if (j + 1 < m.lin_layers && !(amax < 65504.0)) c->f16_ok = false;   // the next feed-forward GEMM would see it
         prev = m.lin_hidden;
@@ -688,8 +695,25 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         if (y_planes(lastl)) { q.Yh = hi_of(w.off_Y[lastl & 1]); q.Yl = lo_of(w.off_Y[lastl & 1], w.Wd); }
         else q.Y = Yf(lastl & 1);
         q.ldy = w.Wd; q.tiles = w.tiles; q.T = T; q.B = B;
+        // the head in the same launch when every feed-forward layer is 128 -> 128 (the default head)
+        bool head_in = d_logits != nullptr && m.lin_layers <= LSTM_STACK_MAX_LIN;
+        for (int j = 0; j < m.lin_layers; ++j) head_in = head_in && c->lin_w_img[j] != nullptr;
+        if (head_in) {
+            for (int j = 0; j < m.lin_layers; ++j) { q.lin_w[j] = c->lin_w_img[j]; q.lin_b[j] = c->lin_b[j]; }
+            q.n_lin = m.lin_layers; q.cls_w = c->cls_w; q.cls_b = c->cls_b; q.slope = m.leaky_slope;
+            q.logits = d_logits; q.probs = d_probs; q.ld_out = ld_out > 0 ? ld_out : T;
+        }
         HIPCHK(c, launch_lstm_stack(q, s));
         c->rec_tile_used = 4;
+        if (head_in) {
+            if (c->timing) {
+                HIPCHK(c, hipEventRecord(c->layer_ev[2 * m.num_layers], s));
+                HIPCHK(c, hipEventRecord(c->ev[2], s));
+                HIPCHK(c, hipEventRecord(c->ev[3], s));
+                c->ev_valid = true;
+            }
+            return UVAD_OK;
+        }
     }
     for (int k = 0; k < (use_stack ? 0 : m.num_layers); ++k) {
         const LayerDev &L = c->layers[k];

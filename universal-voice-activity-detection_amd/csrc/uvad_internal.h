@@ -114,7 +114,7 @@ bool pack_whh16h(const float *w_hh, unsigned *regs, unsigned short *p2, float *w
 
 // ---- lstm_stack.hip: every layer of a causal (one-direction, H = 128) stack for T <= LSTM_STACK_TMAX new frames in ONE launch, carried
 //      (h, c) updated in place: the streaming step (uvad_stream_step).  Exact f32.
-constexpr int LSTM_STACK_TMAX = 4, LSTM_STACK_MAX_LAYERS = 8;
+constexpr int LSTM_STACK_TMAX = 4, LSTM_STACK_MAX_LAYERS = 8, LSTM_STACK_MAX_LIN = 4;
 struct LstmStackArgs {
     const float *feats; int kin0;                 // canonical [B][T][kin0] f32 features
     const float *wih[LSTM_STACK_MAX_LAYERS];      // register images of W_ih (pack_lstm_image, K = kin0 for layer 0, 128 after)
@@ -125,11 +125,18 @@ struct LstmStackArgs {
     float *Y; int ldy;                            // last layer's output: f32 rows (tile-major), or
     unsigned short *Yh, *Yl;                      // its two K-blocked f16 planes of ldy columns (Y == nullptr)
     int tiles, T, B;
+    // optional head in the same launch (logits != nullptr): n_lin feed-forward layers of 128 units (leaky_relu) as register images
+    // (pack_fc_image), the classifier row and bias; logits / probs at canonical [b][t] (b < B), row stride ld_out
+    const float *lin_w[LSTM_STACK_MAX_LIN], *lin_b[LSTM_STACK_MAX_LIN]; int n_lin;
+    const float *cls_w, *cls_b; float slope;
+    float *logits, *probs; int ld_out;
 };
 bool lstm_stack_supported(int hidden, int dirs, int in_dim, int T, int n_layers);
 hipError_t launch_lstm_stack(const LstmStackArgs &a, hipStream_t s);
 size_t lstm_image_elems(int K);
 void pack_lstm_image(const float *w /*[4 * 128][K], torch row order*/, int K, float *out);
+size_t fc_image_elems();                                                   // a 128 x 128 feed-forward matrix as a register image
+void pack_fc_image(const float *w /*[128][128], torch nn.Linear.weight*/, float *out);
 
 // ---- head.hip -----------------------------------------------------------------------------
 // logit = Z[m][:K] . w + b ; prob = sigmoid(logit); written at canonical [b][t] (b < B only).
