@@ -149,6 +149,19 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
     const void *xrow = I16 ? (const void *)(reinterpret_cast<const int16_t *>(a.pcm) + (size_t)b * rstride)
                            : (const void *)(reinterpret_cast<const float *>(a.pcm) + (size_t)b * rstride);
 
+    // streaming rows are virtual (FbankArgs::vs_*): sample p of row b's [tail | chunk] image, as stream_stage_kernel would have staged it
+    auto vs_abs = [&](int p) -> float {
+        if (p >= a.vs_tail) return a.vs_chunk[(size_t)b * a.vs_chunk_len + (p - a.vs_tail)];
+        if (a.vs_first) {   // absolute sample index p - tail in [-tail, 0): mirror of the chunk's head (including the edge sample), zero beyond
+            const int m = a.vs_tail - p;
+            return (m <= a.vs_n_left && m - 1 < a.vs_chunk_len) ? a.vs_chunk[(size_t)b * a.vs_chunk_len + (m - 1)] : 0.0f;
+        }
+        return a.vs_tail_in[(size_t)b * a.vs_tail + p];
+    };
+    const bool virt = !I16 && a.vs_chunk != nullptr;
+    if (virt && blockIdx.x == 0)   // the tail the next step starts from
+        for (int q = tid; q < a.vs_tail; q += 256) a.vs_tail_out[(size_t)b * a.vs_tail + q] = vs_abs(a.vs_chunk_len + q);
+
     // ---- stage the PCM tile (reflect at the utterance edges) --------------------------------
     // All loads of the tile are issued before the first LDS write (ST_IT chunks of 4 samples per
     // thread in flight): a load -> wait -> store loop would pay the HBM latency once per chunk.
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
             const int64_t g = s0 + i;
             v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < need) {
-                bool fast = g >= 0 && g + 3 < a.S;
+                bool fast = !virt && g >= 0 && g + 3 < a.S;
                 if (I16) {
                     const int16_t *p = reinterpret_cast<const int16_t *>(xrow) + g;
                     fast = fast && (reinterpret_cast<uintptr_t>(p) & 7) == 0;
@@ -184,7 +197,7 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
                         if (idx >= a.S) idx = 2 * a.S - 1 - idx;
                         if (idx < 0) idx = 0;
                         if (idx >= a.S) idx = a.S - 1;
-                        e4[e] = pcm_at<I16>(xrow, idx);
+                        e4[e] = virt ? vs_abs((int)idx + a.vs_offset) : pcm_at<I16>(xrow, idx);
                     }
                     v[it] = make_float4(e4[0], e4[1], e4[2], e4[3]);
                 }

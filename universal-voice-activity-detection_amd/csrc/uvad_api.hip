@@ -953,10 +953,13 @@ int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, vo
     const size_t staging_bytes = align_up((size_t)B * (L + chunk) * sizeof(float));
     const StreamPlan plan = stream_plan(c, sc, chunk);
     const int par = plan.parity;
-    HIPCHK(c, launch_stream_stage(d_pcm_chunk, B, chunk, S.tail, n_left, plan.first,
-                                  reinterpret_cast<const float *>(st + S.off_tail[par]),
-                                  reinterpret_cast<float *>(st + S.off_tail[par ^ 1]), staging, s));
     const int k = plan.k;
+    // A step that produces frames reads its rows straight from the chunk and the carried tail inside the feature kernel, which also
+    // writes the next tail (FbankArgs::vs_*); only a step without frames (a short first chunk) runs the staging kernel for the tail.
+    if (k <= 0)
+        HIPCHK(c, launch_stream_stage(d_pcm_chunk, B, chunk, S.tail, n_left, plan.first,
+                                      reinterpret_cast<const float *>(st + S.off_tail[par]),
+                                      reinterpret_cast<float *>(st + S.off_tail[par ^ 1]), staging, s));
     sc.n_samples = plan.n_after;
     sc.n_steps += 1;
     if (k <= 0) return 0;
@@ -968,6 +971,9 @@ int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, vo
     float *feats = reinterpret_cast<float *>(reinterpret_cast<char *>(cws) + w.off_feats);
     FbankArgs fa{};
     fa.pcm = staging + o; fa.pcm_is_i16 = 0; fa.B = B; fa.S = (int64_t)(S.tail + chunk) - o; fa.T = k;
+    fa.vs_chunk = d_pcm_chunk; fa.vs_tail_in = reinterpret_cast<const float *>(st + S.off_tail[par]);
+    fa.vs_tail_out = reinterpret_cast<float *>(st + S.off_tail[par ^ 1]);
+    fa.vs_tail = S.tail; fa.vs_chunk_len = chunk; fa.vs_first = plan.first; fa.vs_n_left = n_left; fa.vs_offset = (int)o;
     fa.row_stride = S.tail + chunk;
     fa.frame_len = L; fa.frame_shift = sh; fa.n_mels = c->fb.n_mels;
     fa.preemph = c->fb.preemph; fa.log_floor = c->fb.log_floor; fa.remove_dc = c->fb.remove_dc; fa.snip_edges = 1;

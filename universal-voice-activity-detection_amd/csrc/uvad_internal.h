@@ -197,6 +197,11 @@ struct FbankArgs {
     // columns [n_mels, plane_w) written as zero) with rows in the classifier's tile-major order, padding sequences zeroed: the A
     // operand of the first projection GEMM (gemm_f16p.hip), bit-identical to what launch_split_features makes of feats
     unsigned short *plane_hi, *plane_lo; int plane_w;
+    // Streaming (uvad_stream_step): instead of pcm the rows are VIRTUAL -- row b = [tail of the previous steps (vs_tail samples; on the
+    // first step the reflection of the chunk's head) | this step's chunk], read from vs_offset on -- and the workgroups of the first
+    // tile also write the next tail (the last vs_tail samples of that row) to vs_tail_out.  vs_chunk == nullptr: plain pcm rows.
+    const float *vs_chunk, *vs_tail_in; float *vs_tail_out;
+    int vs_tail, vs_chunk_len, vs_first, vs_n_left, vs_offset;
     FbankTables tab;
 };
 hipError_t launch_fbank(const FbankArgs &a, hipStream_t s);
