@@ -114,6 +114,16 @@ def test_feature_kernel_has_no_64_bit_lds_operations():
     assert {op for op in lds if op.endswith("_b128")} <= {"ds_write_b128"}      # the PCM tile staging only
 
 
+def test_streaming_stack_kernel_has_no_64_bit_lds_operations():
+    """lstm_stack_kernel runs beside whatever else the GPU is doing (a real-time service shares the card): it stays inside the LDS
+    instruction forms that have run in flight without corruption (32-bit and 128-bit, like lstm_rec_kernel), never the 64-bit ones."""
+    isa = _device_isa("lstm_stack")
+    lds = re.findall(r"^\s+(ds_[a-z0-9_]+)", isa, re.M)
+    assert lds and "lstm_stack_kernel" in isa
+    assert not sorted({op for op in lds if re.search(r"_b64$|_b96$", op)})
+    assert not re.search(r"ScratchSize: [1-9]", isa), "lstm_stack_kernel spills registers"
+
+
 def test_launchers_keep_no_process_global_state():
     """a process may own contexts on several GPUs (include/uvad.h), so launchers must not remember per-process that a
     kernel attribute "has been set" (it belongs to the function ON ONE DEVICE); and the shipped kernels carry no diagnostic
