@@ -256,15 +256,16 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
     print("2-rank rehearsal:", {k: d[k] for k in ("value", "ms_per_step")}, sc)
 
 
-def test_bench_regime_outputs_identical_to_single_calls():
+@pytest.mark.parametrize("mode", ["f16p", "f16p3"])
+def test_bench_regime_outputs_identical_to_single_calls(mode):
     """The headline regime checked for CORRECTNESS, not speed: twelve steps of the cfg-2 batch in flight on twelve hardware queues with
     the throughput recurrence (tools/pipe_check.py in its own process, because the queue count is fixed when HIP starts): every
     step's logits equal a single call's bit for bit.  (A 128x128-tile build of the split-f16 GEMM failed this in 80 of 96 steps --
-    its workgroups corrupted the feature kernel's frames when they shared CUs -- while every single-stream test stayed green.)"""
+    its workgroups corrupted the feature kernel's frames when they shared CUs -- while every single-stream test stayed green.)  Both the default mode and the opt-in three-product mode (its own kernel instances)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "pipe_check.py"), "--steps", "96", "--depth", "12"],
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "pipe_check.py"), "--steps", "96", "--depth", "12", "--mode", mode],
                          env=env, capture_output=True, text=True, timeout=600)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert line, out.stderr[-2000:]
@@ -284,7 +285,7 @@ def test_feature_kernel_beside_a_synthetic_mfma_neighbour():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if not os.path.exists(os.path.join(root, "tools", "libburner.so")):
         pytest.skip("tools/libburner.so not built (python -c 'import __graft_entry__ as g; g.build()')")
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "burner_probe.py"), "fbank", "classify", "sincnet", "forward_wav"],
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "burner_probe.py"), "fbank", "classify", "sincnet", "forward_wav", "stream_step"],
                          capture_output=True, text=True, timeout=900)
     line = [l for l in out.stdout.splitlines() if l.startswith("SUMMARY")]
     assert line, (out.stdout[-1000:], out.stderr[-2000:])
@@ -292,7 +293,8 @@ def test_feature_kernel_beside_a_synthetic_mfma_neighbour():
     print(out.stdout[-600:])
     # sincnet.hip still reads 64-bit LDS fragments (ds_read_b64, the class implicated for the feature kernel): it is held to the same
     # check -- alone, beside the burner, beside a stock f16 GEMM and beside a whole step of another context in flight
-    assert d == {"fbank": 0, "classify": 0, "sincnet": 0, "forward_wav": 0}, d
+    # (stream_step: three 20 ms steps of 512 causal feeds -- the feature kernel on virtual rows and the one-launch LSTM stack + head)
+    assert d == {"fbank": 0, "classify": 0, "sincnet": 0, "forward_wav": 0, "stream_step": 0}, d
 
 
 def test_cfg5_512_feeds_20ms_chunks_equal_offline_and_causal_oracle():

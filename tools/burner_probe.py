@@ -31,6 +31,15 @@ rtw = mw.runtime(dev)
 wav = synth_pcm_device(256, 80000, seed=7, device=dev)
 victims["sincnet"] = lambda: rtw.sincnet(wav)
 victims["forward_wav"] = lambda: rtw.forward_wav(wav, want_probs=False)[0]   # SincNet (64-bit LDS reads) + the classifier, as one pipeline step
+# a streaming step of a causal model (fbank on virtual rows + lstm_stack_kernel: the whole stack and the head in one launch), state reset every time
+mc = uvad_amd.PyanNet2(lstm={"bidirectional": False}, encoding_dim=64); mc.build(); seed_weights(mc, 1234, 4.0)
+mc.attach_fbank(uvad_amd.FbankConfig(num_filters=64, window_type="hamming")); mc = mc.to(dev).eval()
+rtc = mc.runtime(dev)
+chunks = synth_pcm_device(512, 3 * 320, seed=9, device=dev)
+def stream_victim():
+    st = rtc.stream_open(512, 320, graphs=False)
+    return torch.cat([rtc.stream_step(st, chunks[:, i * 320:(i + 1) * 320].contiguous()).clone() for i in range(3)], dim=1)
+victims["stream_step"] = stream_victim
 rt2 = uvad_amd.VadRuntime(device=dev, fbank=m._fbank_cfg, model={"encoding_dim": 64, "lstm": m.hparams.lstm, "linear": m.hparams.linear})
 rt2.load_state_dict(m.state_dict())
 rt2.set_recurrent_tile(16)

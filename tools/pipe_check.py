@@ -15,6 +15,7 @@ ap.add_argument("--seconds", type=float, default=10.0)
 ap.add_argument("--tile", type=int, default=16)
 ap.add_argument("--no-dc", action="store_true")
 ap.add_argument("--stage", default="forward", choices=["forward", "classify", "fbank"])
+ap.add_argument("--mode", default="f16p", choices=["f16p", "f16p3", "f32", "f16p_stream"], help="GEMM mode of every context")
 args = ap.parse_args()
 import uvad_amd
 from uvad_amd import _lib
@@ -27,6 +28,7 @@ m.attach_fbank(uvad_amd.FbankConfig(num_filters=64, window_type="hamming", remov
 pcm = synth_pcm_device(args.batch, int(args.seconds * 16000), seed=42, device=dev)
 rt = m.runtime(dev)
 rt.set_recurrent_tile(args.tile)
+rt.set_gemm_mode(args.mode)
 feats = rt.fbank(pcm)
 def run_one(r):
     if args.stage == "forward": return r.forward(pcm, want_probs=False)[0]
@@ -35,6 +37,7 @@ def run_one(r):
 want = run_one(rt).clone()
 assert torch.equal(want, run_one(rt))
 pipe = uvad_amd.ForwardPipeline(m, dev, depth=args.depth, recurrent_tile=args.tile)
+for r in pipe.runtimes: r.set_gemm_mode(args.mode)
 bad, worst, nseq = 0, 0.0, 0
 for base in range(0, args.steps, args.depth):
     n = min(args.depth, args.steps - base)
@@ -53,6 +56,6 @@ for base in range(0, args.steps, args.depth):
             worst = max(worst, float(d.max()))
             nseq += int((d.reshape(d.shape[0], -1).max(dim=1).values > 0).sum())
 pipe.close()
-print(json.dumps({"lib": args.lib or "default", "depth": args.depth, "tile": args.tile, "batch": args.batch, "steps": args.steps, "stage": args.stage,
+print(json.dumps({"lib": args.lib or "default", "depth": args.depth, "tile": args.tile, "batch": args.batch, "steps": args.steps, "stage": args.stage, "mode": args.mode,
                   "steps_with_wrong_logits": bad, "sequences_affected": nseq, "worst_abs_diff": worst}))
 sys.exit(1 if bad else 0)
