@@ -240,9 +240,10 @@ class VadRuntime:
     # ------------------------------------------------------------------ streaming (BASELINE cfg 5)
     def stream_open(self, B: int, chunk: int, graphs: bool = False):
         """Allocate and reset the carried state of B lock-step streams fed `chunk` samples per step.
-        graphs: replay each distinct step shape as a hipGraph (see stream_step).  Off by default: measured at BASELINE cfg 5
-        (512 feeds, 20 ms chunks) a replayed step takes 0.133 ms against 0.125 ms enqueued kernel by kernel -- the step is bound by
-        the boundaries between its ~14 dependent kernels on the GPU, which a graph does not shorten, not by launch overhead."""
+        graphs: replay each distinct step shape as a hipGraph (see stream_step).  Off by default: a step of a causal 128-unit model
+        is two launches (the feature kernel and lstm_stack_kernel: every layer and the head), 0.061 ms at BASELINE cfg 5 (512 feeds,
+        20 ms chunks); a graph has nothing left to shorten (with the 14 per-layer launches of round 2 a replayed step took 0.133 ms
+        against 0.125 ms enqueued kernel by kernel)."""
         with torch.cuda.device(self.device):
             nbytes = int(self.lib.uvad_stream_state_bytes(self.ctx, B))
             if nbytes == 0:
