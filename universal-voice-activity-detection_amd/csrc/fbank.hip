@@ -24,12 +24,15 @@
 //   8.9 G frames/s the HBM roofline would allow.
 //   Algorithmic HBM bytes per frame: 640 read (320 for int16 PCM) + 4*n_mels written.
 #include "uvad_internal.h"
+#include "fbank_pair.h"
 
 namespace uvad {
 
 namespace {
 
-constexpr int NFFT = 512;
+using fbp::NFFT;
+using fbp::ZB_ELEMS;
+using fbp::wave_lds_fence;
 #ifndef UVAD_FB_PAIRS
 #define UVAD_FB_PAIRS 3    // frame pairs per wave: 24 frames per workgroup (16 KiB PCM tile; with the scratch ~43 KiB of LDS -> 3 workgroups per CU)
 #endif
@@ -38,78 +41,8 @@ constexpr int NFFT = 512;
 #endif
 constexpr int PAIRS_PER_WAVE = UVAD_FB_PAIRS;
 constexpr int FR_WG = 4 * 2 * PAIRS_PER_WAVE;  // frames per workgroup
-constexpr int ZB_LD = 9;                       // padded row (8 complex + 1) of the transpose scratch
-constexpr int ZB_ELEMS = 64 * ZB_LD;           // 576 complex >= 512
 constexpr int PB_ELEMS = 0;                    // the 257 (powerA, powerB) pairs reuse the first 264 slots of the transpose scratch
 
-__device__ __forceinline__ void wave_lds_fence() {
-    // Hand-off through the wave's own LDS scratch.  The hardware executes one wave's DS operations in
-    // issue order, so a ds_read issued after a ds_write of the same wave sees the written data; all that
-    // is needed is that the COMPILER keeps that order.  (A release/acquire fence pair here, even at
-    // wavefront scope, made hipcc drain vmcnt(0) -- i.e. wait for the feature stores of the previous
-    // frame pair to reach memory -- at every hand-off.)
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-}
-
-// Wave-wide sum as a wave-uniform value, on the VALU (DPP), not through the LDS crossbar: four
-// xor-style steps give every lane its 16-lane row total, two row broadcasts accumulate the rows into
-// lane 63, a readlane returns it.  (A ds_bpermute butterfly costs an LDS round trip per step.)
-#define UVAD_DPP_ADD(V, CTRL, ROW_MASK)                                                                   \
-    V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, ROW_MASK, 0xF, true))
-__device__ __forceinline__ float wave_sum(float v) {
-    UVAD_DPP_ADD(v, 0xB1, 0xF);    // quad_perm [1,0,3,2]
-    UVAD_DPP_ADD(v, 0x4E, 0xF);    // quad_perm [2,3,0,1]
-    UVAD_DPP_ADD(v, 0x141, 0xF);   // row_half_mirror
-    UVAD_DPP_ADD(v, 0x140, 0xF);   // row_mirror: every lane holds its row total
-    UVAD_DPP_ADD(v, 0x142, 0xA);   // row_bcast:15 into rows 1 and 3
-    UVAD_DPP_ADD(v, 0x143, 0xC);   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave total
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-
-// forward 8-point DFT, in place: out[q] = sum_r in[r] * exp(-2*pi*i*r*q/8)
-__device__ __forceinline__ void dft8(float (&re)[8], float (&im)[8]) {
-    constexpr float R = 0.70710678118654752f;
-    float ar[4], ai[4], br[4], bi[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        ar[j] = re[j] + re[j + 4];
-        ai[j] = im[j] + im[j + 4];
-        br[j] = re[j] - re[j + 4];
-        bi[j] = im[j] - im[j + 4];
-    }
-    // b_j *= W8^j
-    {
-        const float t1r = (br[1] + bi[1]) * R, t1i = (bi[1] - br[1]) * R;  // * (1 - i)/sqrt2
-        br[1] = t1r; bi[1] = t1i;
-        const float t2r = bi[2], t2i = -br[2];                              // * (-i)
-        br[2] = t2r; bi[2] = t2i;
-        const float t3r = (bi[3] - br[3]) * R, t3i = -(br[3] + bi[3]) * R; // * (-1 - i)/sqrt2
-        br[3] = t3r; bi[3] = t3i;
-    }
-    // 4-point DFTs: even outputs from a, odd outputs from b
-    {
-        const float s0r = ar[0] + ar[2], s0i = ai[0] + ai[2];
-        const float s1r = ar[0] - ar[2], s1i = ai[0] - ai[2];
-        const float s2r = ar[1] + ar[3], s2i = ai[1] + ai[3];
-        const float s3r = ai[1] - ai[3], s3i = -(ar[1] - ar[3]);           // (a1 - a3) * (-i)
-        re[0] = s0r + s2r; im[0] = s0i + s2i;
-        re[4] = s0r - s2r; im[4] = s0i - s2i;
-        re[2] = s1r + s3r; im[2] = s1i + s3i;
-        re[6] = s1r - s3r; im[6] = s1i - s3i;
-    }
-    {
-        const float s0r = br[0] + br[2], s0i = bi[0] + bi[2];
-        const float s1r = br[0] - br[2], s1i = bi[0] - bi[2];
-        const float s2r = br[1] + br[3], s2i = bi[1] + bi[3];
-        const float s3r = bi[1] - bi[3], s3i = -(br[1] - br[3]);
-        re[1] = s0r + s2r; im[1] = s0i + s2i;
-        re[5] = s0r - s2r; im[5] = s0i - s2i;
-        re[3] = s1r + s3r; im[3] = s1i + s3i;
-        re[7] = s1r - s3r; im[7] = s1i - s3i;
-    }
-}
 
 template <bool I16>
 __device__ __forceinline__ float pcm_at(const void *row, int64_t i) {
@@ -212,30 +145,10 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
     // mel weights as [bin-in-band][filter] (transposed and zero-padded to whole pairs on the host), so lane m reads conflict-free
     for (int i = tid; i < 2 * mel_pairs * F; i += 256) melw[i] = a.tab.mel_wt[i];
 
-    // ---- per-lane constants -------------------------------------------------------------------
-    float win[8];
-    float2 tw1[8], tw2[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int n = lane + 64 * r;
-        win[r] = n < L ? a.tab.window[n] : 0.0f;
-        tw1[r] = tw512[(lane * r) & (NFFT - 1)];
-        tw2[r] = tw512[(8 * (lane & 7) * r) & (NFFT - 1)];
-    }
+    // ---- per-lane constants (fbank_pair.h: window taps, twiddles, band starts; retired before the frame loop) ----------------
+    fbp::PairConsts kc;
+    fbp::load_pair_consts(kc, a.tab, tw512, lane, L, F);
     const int nfilt_pass = (F + 63) / 64;
-    // band starts of this lane's filters (passes 0 and 1 cover n_mels <= 128): loaded ONCE per workgroup.
-    // Inside the frame loop a global load would also make hipcc drain vmcnt(0), i.e. wait for the feature
-    // stores of the previous frame pair, every pair.
-    const int mst0 = a.tab.mel_start[lane < F ? lane : F - 1];
-    int mst1 = a.tab.mel_start[lane + 64 < F ? lane + 64 : F - 1];
-    int mst0v = mst0;
-    // Retire every global load issued so far BEFORE the frame loop: a register that is still "in flight"
-    // at loop entry makes hipcc put s_waitcnt vmcnt(0) at its first use INSIDE the loop, where it then
-    // also waits for the feature stores of the previous frame pair on every iteration.
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-        asm volatile("" : "+v"(win[r]), "+v"(tw1[r].x), "+v"(tw1[r].y), "+v"(tw2[r].x), "+v"(tw2[r].y));
-    asm volatile("" : "+v"(mst0v), "+v"(mst1));
     __syncthreads();
     // Per-wave scratch as TWO 4-byte arrays (real / imaginary parts of the transform; later the power of frame A / frame B), never
     // as float2 pairs: every LDS instruction of this kernel is a 32-bit one (ds_read_b32 / ds_read2_b32 / ds_write2_b32 ...).
@@ -244,8 +157,6 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
     // flight) -- the same happens to stock rocFFT, and the 32-bit form is immune (DESIGN.md section 3.3,
     // profiles/r02_concurrency_corruption.json).  It is also 3 % faster.
     float *zr = reinterpret_cast<float *>(wscr + (size_t)wave * (ZB_ELEMS + PB_ELEMS)), *zi = zr + ZB_ELEMS;
-#define ZB_PUT(idx, a, b) { zr[idx] = (a); zi[idx] = (b); }
-#define ZB_GET(idx) make_float2(zr[idx], zi[idx])
     const float inv_len = 1.0f / (float)L;
 
     for (int q = 0; q < PAIRS_PER_WAVE; ++q) {
@@ -255,125 +166,9 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
         const float *xa = raw + fa * sh;
         const float *xb = raw + (has_b ? fa + 1 : fa) * sh;
 
-        // ---- framing, DC removal, pre-emphasis, window: lane p owns n = p + 64 r ---------------
-        float re[8], im[8], pa[8], pbv[8];
-        float suma = 0.f, sumb = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            // unconditional LDS reads (index clamped into the frame); samples past the frame are
-            // zeroed by a select for the mean and by the zero window tap for the spectrum
-            const int n = lane + 64 * r;
-            const bool in = n < L;
-            const int nc = in ? n : L - 1;
-            const int np = nc > 0 ? nc - 1 : 0;
-            const float va = xa[nc], vpa = xa[np], vb = xb[nc], vpb = xb[np];
-            re[r] = in ? va : 0.f;
-            pa[r] = vpa;
-            im[r] = in ? vb : 0.f;
-            pbv[r] = vpb;
-            suma += re[r];
-            sumb += im[r];
-        }
-        float mua = 0.f, mub = 0.f;
-        if (a.remove_dc) {
-            mua = wave_sum(suma) * inv_len;
-            mub = wave_sum(sumb) * inv_len;
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            re[r] = ((re[r] - mua) - a.preemph * (pa[r] - mua)) * win[r];
-            im[r] = has_b ? ((im[r] - mub) - a.preemph * (pbv[r] - mub)) * win[r] : 0.f;
-        }
-        // ---- pass 1: DFT over n1 (n = 64 n1 + p), twiddle W512^(p k1) ----------------------------
-        dft8(re, im);
-#pragma unroll
-        for (int k = 1; k < 8; ++k) {
-            const float r0 = re[k] * tw1[k].x - im[k] * tw1[k].y;
-            const float i0 = re[k] * tw1[k].y + im[k] * tw1[k].x;
-            re[k] = r0; im[k] = i0;
-        }
-        // transpose: lane p = 8a + b -> element k1 goes to row (k1, b), column a
-        {
-            const int aa = lane >> 3, bb = lane & 7;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) ZB_PUT((k * 8 + bb) * ZB_LD + aa, re[k], im[k]);
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float2 v = ZB_GET(lane * ZB_LD + k);
-            re[k] = v.x; im[k] = v.y;
-        }
-        // ---- pass 2: lane (k1, b): DFT over a -> c, twiddle W64^(b c) -----------------------------
-        dft8(re, im);
-#pragma unroll
-        for (int k = 1; k < 8; ++k) {
-            const float r0 = re[k] * tw2[k].x - im[k] * tw2[k].y;
-            const float i0 = re[k] * tw2[k].y + im[k] * tw2[k].x;
-            re[k] = r0; im[k] = i0;
-        }
-        wave_lds_fence();  // all reads of the scratch are issued before it is rewritten
-        {
-            const int k1 = lane >> 3, bb = lane & 7;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) ZB_PUT((k1 * 8 + c) * ZB_LD + bb, re[c], im[c]);
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float2 v = ZB_GET(lane * ZB_LD + k);
-            re[k] = v.x; im[k] = v.y;
-        }
-        // ---- pass 3: lane (k1, c): DFT over b -> d; Z[k1 + 8c + 64d] -------------------------------
-        dft8(re, im);
-        wave_lds_fence();
-        {
-            const int lam = (lane >> 3) + 8 * (lane & 7);
-#pragma unroll
-            for (int d = 0; d < 8; ++d) ZB_PUT(lam + 64 * d, re[d], im[d]);
-        }
-        wave_lds_fence();
-        // ---- split the two real spectra, power: A = (Z[k] + conj Z[N-k])/2, B = (Z[k] - conj Z[N-k])/(2i)
-        // (all reads first, then the power pairs overwrite the scratch)
-        {
-            float2 pw[5];
-#pragma unroll
-            for (int d = 0; d < 5; ++d) {
-                const int k = lane + 64 * d;
-                const int kc = d < 4 ? k : (lane == 0 ? 256 : 0);
-                const float2 z = ZB_GET(kc);
-                const float2 w = ZB_GET((NFFT - kc) & (NFFT - 1));
-                const float ar = z.x + w.x, ai = z.y - w.y;
-                const float br = z.y + w.y, bi = z.x - w.x;
-                pw[d] = make_float2(0.25f * (ar * ar + ai * ai), 0.25f * (br * br + bi * bi));
-            }
-            wave_lds_fence();
-#pragma unroll
-            for (int d = 0; d < 5; ++d)
-                if (d < 4 || lane == 0) ZB_PUT(lane + 64 * d, pw[d].x, pw[d].y);
-        }
-        wave_lds_fence();
-        // ---- mel band sums + log; lane = filter ----------------------------------------------------
-        // Uniform trip count (the longest band, zero-padded weights), two bins per LDS instruction: the weights of bins i, i+1
-        // are F floats apart (ds_read2_b32), their power pairs adjacent (ds_read2_b64, no alignment requirement).  No clamp of
-        // the bin index: a band that runs past bin 256 reads this pair's own spectrum values from the scratch (finite) against
-        // zero weights.
-        for (int ps = 0; ps < nfilt_pass; ++ps) {
-            const int m = lane + 64 * ps;
-            const int mm = m < F ? m : F - 1;
-            const int st = ps == 0 ? mst0v : mst1;   // n_mels <= 128 (checked by uvad_create): no global load in this loop
-            float ea = 0.f, eb = 0.f, ea2 = 0.f, eb2 = 0.f;
-            const float *wp = melw + mm;
-            for (int i = 0; i < mel_pairs; ++i) {
-                const float w0 = wp[(2 * i) * F], w1 = wp[(2 * i + 1) * F];
-                const float2 p0 = ZB_GET(st + 2 * i), p1 = ZB_GET(st + 2 * i + 1);
-                ea = __builtin_fmaf(w0, p0.x, ea);
-                eb = __builtin_fmaf(w0, p0.y, eb);
-                ea2 = __builtin_fmaf(w1, p1.x, ea2);
-                eb2 = __builtin_fmaf(w1, p1.y, eb2);
-            }
-            ea += ea2;
-            eb += eb2;
+        // ---- the pair's transform, spectrum split, power and mel band sums (fbank_pair.h); per filter pass every lane gets its two band energies
+        fbp::fbank_pair(xa, xb, has_b, kc, zr, zi, melw, mel_pairs, nfilt_pass, F, L, a.preemph, a.remove_dc != 0, inv_len, lane, [&](int m, float ea, float eb) {
+
             // ocml logf (<= 1 ulp), not the 2-ulp-of-log2 __logf: two per lane and frame pair, nothing next to the FFT
             if (a.plane_hi) {
                 // straight into the operand planes of the first projection GEMM (gemm_f16p.hip: x ~= hi + lo * 2^-11, K-blocked, rows in
@@ -397,7 +192,7 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
                 o[0] = logf(fmaxf(ea, a.log_floor));
                 if (has_b) o[F] = logf(fmaxf(eb, a.log_floor));
             }
-        }
+        });
         wave_lds_fence();
     }
 }

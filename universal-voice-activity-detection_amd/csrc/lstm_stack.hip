@@ -15,6 +15,7 @@
 // Exact f32 throughout (the MFMA is a k-ordered fmaf chain); the weights (about 2 MB per workgroup at 4 x 128 units) come from L2.
 // The last layer's h_t leaves as the two K-blocked f16 planes the fused head reads (or f32 rows).
 #include "uvad_internal.h"
+#include "fbank_pair.h"
 
 namespace uvad {
 
@@ -89,8 +90,10 @@ __device__ __forceinline__ void load_image(float (&w)[H], const float *img, int 
 }
 
 // KIN0: feature width (columns of layer 0's W_ih): 64 or 80 (other widths: the per-layer kernels)
-template <int KIN0, bool PLANES>
+// FB: the feature stage runs in this launch (LstmStackArgs::fb; only with the head in the launch too, so PLANES is false then)
+template <int KIN0, bool PLANES, bool FB>
 __global__ __launch_bounds__(WAVES * 64) void lstm_stack_kernel(LstmStackArgs a) {
+    static_assert(!(FB && PLANES), "the feature stage comes with the in-launch head: no plane output");
     constexpr int TMAX = LSTM_STACK_TMAX;
     constexpr int HR = KIN0 == 64 ? 4 : 2;
     __shared__ __attribute__((aligned(16))) float xbuf[TMAX][SEQ_TILE][HS];   // input of the current layer, frame by frame
@@ -104,6 +107,51 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_stack_kernel(LstmStackArgs a)
     const int unit = wave * 16 + blk;
     const int T = a.T;
 
+    if constexpr (FB) {
+        // ---- the feature stage in this launch (fbank_pair.h): the step's rows are virtual -- [carried tail | this step's chunk], as in
+        //      fbank_kernel's streaming form (FbankArgs::vs_*) -- and belong to this workgroup alone: its 4 sequences x T <= 4 frames are
+        //      8 frame pairs at most, one per wave (row = wave / 2, pair = wave % 2), written straight into xbuf.
+        extern __shared__ __attribute__((aligned(16))) float fbs[];
+        const FbankArgs &f = a.fb;
+        const int L = f.frame_len, sh = f.frame_shift, F = KIN0;
+        const int need = (T - 1) * sh + L, raw_ld = (need + 3) & ~3;
+        const int mel_pairs = (f.tab.mel_stride + 1) / 2;
+        float *raw = fbs, *melw = raw + SEQ_TILE * raw_ld, *scr = melw + ((2 * mel_pairs * F + 3) & ~3);
+        auto vs_abs = [&](int b, int p) -> float {   // sample p of row b's [tail | chunk] image (see fbank.hip)
+            if (b >= a.B) return 0.0f;
+            if (p >= f.vs_tail) return f.vs_chunk[(size_t)b * f.vs_chunk_len + (p - f.vs_tail)];
+            if (f.vs_first) {
+                const int m = f.vs_tail - p;
+                return (m <= f.vs_n_left && m - 1 < f.vs_chunk_len) ? f.vs_chunk[(size_t)b * f.vs_chunk_len + (m - 1)] : 0.0f;
+            }
+            return f.vs_tail_in[(size_t)b * f.vs_tail + p];
+        };
+        for (int i = tid; i < SEQ_TILE * need; i += WAVES * 64) {
+            const int j = i / need, q = i - j * need;
+            raw[j * raw_ld + q] = vs_abs(tile * SEQ_TILE + j, q + f.vs_offset);
+        }
+        for (int i = tid; i < SEQ_TILE * f.vs_tail; i += WAVES * 64) {   // the tail the next step starts from
+            const int j = i / f.vs_tail, q = i - j * f.vs_tail, b = tile * SEQ_TILE + j;
+            if (b < a.B) f.vs_tail_out[(size_t)b * f.vs_tail + q] = vs_abs(b, f.vs_chunk_len + q);
+        }
+        for (int i = tid; i < 2 * mel_pairs * F; i += WAVES * 64) melw[i] = f.tab.mel_wt[i];
+        fbp::PairConsts kc;
+        fbp::load_pair_consts(kc, f.tab, reinterpret_cast<const float2 *>(f.tab.tw512), lane, L, F);
+        __syncthreads();
+        const int j = wave >> 1, fa = 2 * (wave & 1);
+        if (fa < T) {   // wave-uniform
+            const bool has_b = fa + 1 < T;
+            float *zr = scr + (size_t)wave * (2 * fbp::ZB_ELEMS), *zi = zr + fbp::ZB_ELEMS;
+            fbp::fbank_pair(raw + j * raw_ld + fa * sh, raw + j * raw_ld + (has_b ? fa + 1 : fa) * sh, has_b, kc, zr, zi, melw, mel_pairs,
+                            (F + 63) / 64, F, L, f.preemph, f.remove_dc != 0, 1.0f / (float)L, lane, [&](int m, float ea, float eb) {
+                                if (m < F) {
+                                    xbuf[fa][j][m] = logf(fmaxf(ea, f.log_floor));
+                                    if (has_b) xbuf[fa + 1][j][m] = logf(fmaxf(eb, f.log_floor));
+                                }
+                            });
+        }
+        // (the __syncthreads() in front of layer 0's chains publishes xbuf)
+    } else
     // ---- the features of the tile's 4 sequences (canonical [B][T][KIN0]; rows of padding sequences read as zero)
     for (int i = tid; i < T * SEQ_TILE * (KIN0 / 4); i += WAVES * 64) {
         const int q = i % (KIN0 / 4), j = (i / (KIN0 / 4)) % SEQ_TILE, t = i / (KIN0 / 4 * SEQ_TILE);
@@ -234,6 +282,14 @@ void pack_lstm_image(const float *wm, int K, float *out) {
                 }
 }
 
+size_t lstm_stack_fb_lds_bytes(const FbankArgs &fb, int T) {
+    if (!fb.vs_chunk || !fb.tab.mel_wt || !fb.tab.tw512 || T < 1 || T > LSTM_STACK_TMAX || fb.n_mels > 128) return 0;
+    const size_t need = (size_t)(T - 1) * fb.frame_shift + fb.frame_len, raw_ld = (need + 3) & ~(size_t)3;
+    const size_t melw = (size_t)((2 * ((fb.tab.mel_stride + 1) / 2) * fb.n_mels + 3) & ~3);
+    const size_t bytes = (SEQ_TILE * raw_ld + melw + (size_t)WAVES * 2 * fbp::ZB_ELEMS) * sizeof(float);
+    return bytes <= 120 * 1024 ? bytes : 0;
+}
+
 bool lstm_stack_supported(int hidden, int dirs, int in_dim, int T, int n_layers) {
     return hidden == H && dirs == 1 && (in_dim == 64 || in_dim == 80) && T >= 1 && T <= LSTM_STACK_TMAX && n_layers >= 1 &&
            n_layers <= LSTM_STACK_MAX_LAYERS;
@@ -241,15 +297,28 @@ bool lstm_stack_supported(int hidden, int dirs, int in_dim, int T, int n_layers)
 
 hipError_t launch_lstm_stack(const LstmStackArgs &a, hipStream_t s) {
     if (a.tiles <= 0 || a.T <= 0) return hipSuccess;
-    if (!lstm_stack_supported(H, 1, a.kin0, a.T, a.n_layers) || !a.feats || !a.h || !a.c) return hipErrorInvalidValue;
+    if (!lstm_stack_supported(H, 1, a.kin0, a.T, a.n_layers) || (!a.feats && !a.fb_on) || !a.h || !a.c) return hipErrorInvalidValue;
     if ((long long)a.tiles * SEQ_TILE * a.T * (a.ldy > H ? a.ldy : H) >= (1LL << 31)) return hipErrorInvalidValue;   // 32-bit offsets in the kernel
     const bool planes = a.Y == nullptr;
     if (!a.logits && planes && (!a.Yh || !a.Yl)) return hipErrorInvalidValue;
     if (a.logits && (a.n_lin < 0 || a.n_lin > LSTM_STACK_MAX_LIN || !a.cls_w || !a.cls_b || a.ld_out < a.T)) return hipErrorInvalidValue;
+    size_t lds = 0;
+    if (a.fb_on) {
+        lds = lstm_stack_fb_lds_bytes(a.fb, a.T);
+        if (!lds || a.fb.n_mels != a.kin0 || !a.logits) return hipErrorInvalidValue;
+    }
     const dim3 grid(a.tiles), block(WAVES * 64);
-#define UVAD_STACK_LAUNCH(K_)                                                                  \
-    if (planes) hipLaunchKernelGGL((lstm_stack_kernel<K_, true>), grid, block, 0, s, a);      \
-    else hipLaunchKernelGGL((lstm_stack_kernel<K_, false>), grid, block, 0, s, a);
+    // (the dynamic-LDS attribute belongs to the (function, device) pair: set for the current device on every launch that needs it)
+#define UVAD_STACK_LAUNCH(K_)                                                                                                              \
+    if (a.fb_on) {                                                                                                                         \
+        if (lds > 40 * 1024) {                                                                                                             \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lstm_stack_kernel<K_, false, true>),                   \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+            if (e != hipSuccess) return e;                                                                                                 \
+        }                                                                                                                                  \
+        hipLaunchKernelGGL((lstm_stack_kernel<K_, false, true>), grid, block, lds, s, a);                                                  \
+    } else if (planes) hipLaunchKernelGGL((lstm_stack_kernel<K_, true, false>), grid, block, 0, s, a);                                     \
+    else hipLaunchKernelGGL((lstm_stack_kernel<K_, false, false>), grid, block, 0, s, a);
     switch (a.kin0) {
         case 64: UVAD_STACK_LAUNCH(64) break;
         case 80: UVAD_STACK_LAUNCH(80) break;

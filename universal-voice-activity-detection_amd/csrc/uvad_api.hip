@@ -551,7 +551,7 @@ int uvad_sincnet(uvad_ctx *c, const float *d_wav, int B, int64_t S, float *d_fea
 
 static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float *d_logits, float *d_probs,
                          void *ws, size_t ws_bytes, hipStream_t s, bool record_start, bool check_range,
-                         const StreamState *ss, int ld_out, bool feats_in_planes);
+                         const StreamState *ss, int ld_out, bool feats_in_planes, const FbankArgs *fused_fb);
 
 int uvad_forward_wav(uvad_ctx *c, const float *d_wav, int B, int64_t S, float *d_logits, float *d_probs,
                      void *ws, size_t ws_bytes, void *stream) {
@@ -571,7 +571,7 @@ int uvad_forward_wav(uvad_ctx *c, const float *d_wav, int B, int64_t S, float *d
     if (c->timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
     int r = sincnet_impl(c, d_wav, B, S, feats, base + w.total, ws_bytes - w.total, s);
     if (r) return r;
-    return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, w.total, s, false, true, nullptr, 0, false);
+    return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, w.total, s, false, true, nullptr, 0, false, nullptr);
 }
 
 int64_t uvad_num_frames(const uvad_ctx *c, int64_t S) {
@@ -657,12 +657,21 @@ static bool stream_uses_stack(const uvad_ctx *c, int T) {
     return true;
 }
 
+// ... and its feed-forward layers + classifier inside that launch (every feed-forward layer 128 x 128)
+static bool stream_head_in_stack(const uvad_ctx *c) {
+    const uvad_model_cfg &m = c->mc;
+    if (m.lin_layers > LSTM_STACK_MAX_LIN) return false;
+    for (int j = 0; j < m.lin_layers; ++j)
+        if (!c->lin_w_img[j]) return false;
+    return true;
+}
+
 // check_range: the features come from the caller (or from a front end with learnable scales) and may lie outside the f16
 // range; the split-f16 layer-0 projection is then replaced by the exact-f32 one ON THE DEVICE (both are enqueued, a flag
 // written by range_flag_kernel lets exactly one of them run), so the call stays asynchronous and capturable.
 static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float *d_logits, float *d_probs,
                          void *ws, size_t ws_bytes, hipStream_t s, bool record_start, bool check_range,
-                         const StreamState *ss = nullptr, int ld_out = 0, bool feats_in_planes = false) {
+                         const StreamState *ss, int ld_out, bool feats_in_planes, const FbankArgs *fused_fb) {
     const uvad_model_cfg &m = c->mc;
     const WsLayout w = carve(c, B, T);
     if (ws_bytes < w.total) return fail(c, UVAD_E_WORKSPACE, "workspace too small: need " + std::to_string(w.total) + " bytes");
@@ -696,8 +705,9 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         else q.Y = Yf(lastl & 1);
         q.ldy = w.Wd; q.tiles = w.tiles; q.T = T; q.B = B;
         // the head in the same launch when every feed-forward layer is 128 -> 128 (the default head)
-        bool head_in = d_logits != nullptr && m.lin_layers <= LSTM_STACK_MAX_LIN;
-        for (int j = 0; j < m.lin_layers; ++j) head_in = head_in && c->lin_w_img[j] != nullptr;
+        const bool head_in = d_logits != nullptr && stream_head_in_stack(c);
+        if (fused_fb && !head_in) return fail(c, UVAD_E_STATE, "internal: fused feature stage without the in-launch head");
+        if (fused_fb) { q.fb = *fused_fb; q.fb_on = 1; }   // the feature stage in the same launch (uvad_stream_step decided)
         if (head_in) {
             for (int j = 0; j < m.lin_layers; ++j) { q.lin_w[j] = c->lin_w_img[j]; q.lin_b[j] = c->lin_b[j]; }
             q.n_lin = m.lin_layers; q.cls_w = c->cls_w; q.cls_b = c->cls_b; q.slope = m.leaky_slope;
@@ -802,7 +812,7 @@ int uvad_classify(uvad_ctx *c, const float *d_feats, int B, int T, float *d_logi
     if (!d_feats || B <= 0 || T <= 0 || !ws) return fail(c, UVAD_E_ARG, "uvad_classify: bad argument");
     if (!c->finalized) return fail(c, UVAD_E_STATE, "uvad_classify: uvad_finalize has not been called");
     HIPCHK(c, hipSetDevice(c->device));
-    return classify_impl(c, d_feats, B, T, d_logits, d_probs, ws, ws_bytes, (hipStream_t)stream, true, true);
+    return classify_impl(c, d_feats, B, T, d_logits, d_probs, ws, ws_bytes, (hipStream_t)stream, true, true, nullptr, 0, false, nullptr);
 }
 
 static int forward_impl(uvad_ctx *c, const void *d_pcm, int is_i16, int B, int64_t S, float *d_logits, float *d_probs,
@@ -827,7 +837,7 @@ static int forward_impl(uvad_ctx *c, const void *d_pcm, int is_i16, int B, int64
     int r = planes ? fbank_impl(c, d_pcm, is_i16, B, S, nullptr, stream, ph, ph + plane_rows(w.M) * (size_t)w.Fp, w.Fp)
                    : fbank_impl(c, d_pcm, is_i16, B, S, feats, stream);
     if (r) return r;
-    return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, ws_bytes, s, false, false, nullptr, 0, planes);
+    return classify_impl(c, feats, B, (int)T, d_logits, d_probs, ws, ws_bytes, s, false, false, nullptr, 0, planes, nullptr);
 }
 
 int uvad_forward(uvad_ctx *c, const float *d_pcm, int B, int64_t S, float *d_logits, float *d_probs,
@@ -987,13 +997,15 @@ int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, vo
     }
     fa.tab.window = c->d_window; fa.tab.mel_start = c->d_mel_start; fa.tab.mel_len = c->d_mel_len;
     fa.tab.mel_w = c->d_mel_w; fa.tab.mel_wt = c->d_mel_wt; fa.tab.mel_stride = c->mel_stride; fa.tab.tw512 = c->d_tw512;
-    HIPCHK(c, launch_fbank(fa, s));
+    // One launch for the whole step when the stack kernel also takes the head and the feature stage fits beside it (lstm_stack.hip)
+    const bool fuse_fb = !planes && stream_uses_stack(c, k) && stream_head_in_stack(c) && lstm_stack_fb_lds_bytes(fa, k) > 0;
+    if (!fuse_fb) HIPCHK(c, launch_fbank(fa, s));
     StreamState ss;
     ss.h = reinterpret_cast<float *>(st + S.off_h); ss.c = reinterpret_cast<float *>(st + S.off_c);
     ss.layer_stride = S.layer_stride / sizeof(float);
     const bool timing = c->timing;
     c->timing = false;
-    const int r = classify_impl(c, feats, B, k, d_logits, nullptr, cws, ws_bytes - staging_bytes, s, false, false, &ss, ld_logits, planes);
+    const int r = classify_impl(c, feats, B, k, d_logits, nullptr, cws, ws_bytes - staging_bytes, s, false, false, &ss, ld_logits, planes, fuse_fb ? &fa : nullptr);
     c->timing = timing;
     return r < 0 ? r : k;
 }

@@ -112,32 +112,6 @@ size_t whh16h_regs_elems();
 size_t whh16h_p2_elems();
 bool pack_whh16h(const float *w_hh, unsigned *regs, unsigned short *p2, float *wscale);   // false: a weight is non-finite
 
-// ---- lstm_stack.hip: every layer of a causal (one-direction, H = 128) stack for T <= LSTM_STACK_TMAX new frames in ONE launch, carried
-//      (h, c) updated in place: the streaming step (uvad_stream_step).  Exact f32.
-constexpr int LSTM_STACK_TMAX = 4, LSTM_STACK_MAX_LAYERS = 8, LSTM_STACK_MAX_LIN = 4;
-struct LstmStackArgs {
-    const float *feats; int kin0;                 // canonical [B][T][kin0] f32 features
-    const float *wih[LSTM_STACK_MAX_LAYERS];      // register images of W_ih (pack_lstm_image, K = kin0 for layer 0, 128 after)
-    const float *whh[LSTM_STACK_MAX_LAYERS];      // register images of W_hh (pack_whh)
-    const float *bias[LSTM_STACK_MAX_LAYERS];     // [4H] b_ih + b_hh in (unit, gate) order
-    int n_layers;
-    float *h, *c; size_t layer_stride;            // carried state [layer][tiles * SEQ_TILE][128] (layer_stride floats apart)
-    float *Y; int ldy;                            // last layer's output: f32 rows (tile-major), or
-    unsigned short *Yh, *Yl;                      // its two K-blocked f16 planes of ldy columns (Y == nullptr)
-    int tiles, T, B;
-    // optional head in the same launch (logits != nullptr): n_lin feed-forward layers of 128 units (leaky_relu) as register images
-    // (pack_fc_image), the classifier row and bias; logits / probs at canonical [b][t] (b < B), row stride ld_out
-    const float *lin_w[LSTM_STACK_MAX_LIN], *lin_b[LSTM_STACK_MAX_LIN]; int n_lin;
-    const float *cls_w, *cls_b; float slope;
-    float *logits, *probs; int ld_out;
-};
-bool lstm_stack_supported(int hidden, int dirs, int in_dim, int T, int n_layers);
-hipError_t launch_lstm_stack(const LstmStackArgs &a, hipStream_t s);
-size_t lstm_image_elems(int K);
-void pack_lstm_image(const float *w /*[4 * 128][K], torch row order*/, int K, float *out);
-size_t fc_image_elems();                                                   // a 128 x 128 feed-forward matrix as a register image
-void pack_fc_image(const float *w /*[128][128], torch nn.Linear.weight*/, float *out);
-
 // ---- head.hip -----------------------------------------------------------------------------
 // logit = Z[m][:K] . w + b ; prob = sigmoid(logit); written at canonical [b][t] (b < B only).
 struct ClsArgs {
@@ -210,6 +184,37 @@ size_t fbank_lds_bytes(const FbankArgs &a);
 // new tail = last `tail` samples of staging
 hipError_t launch_stream_stage(const float *chunk_pcm, int B, int chunk, int tail, int n_left, int first_step,
                                const float *tail_in, float *tail_out, float *staging, hipStream_t s);
+
+// ---- lstm_stack.hip: every layer of a causal (one-direction, H = 128) stack for T <= LSTM_STACK_TMAX new frames in ONE launch, carried
+//      (h, c) updated in place: the streaming step (uvad_stream_step).  Exact f32.
+constexpr int LSTM_STACK_TMAX = 4, LSTM_STACK_MAX_LAYERS = 8, LSTM_STACK_MAX_LIN = 4;
+struct LstmStackArgs {
+    const float *feats; int kin0;                 // canonical [B][T][kin0] f32 features
+    const float *wih[LSTM_STACK_MAX_LAYERS];      // register images of W_ih (pack_lstm_image, K = kin0 for layer 0, 128 after)
+    const float *whh[LSTM_STACK_MAX_LAYERS];      // register images of W_hh (pack_whh)
+    const float *bias[LSTM_STACK_MAX_LAYERS];     // [4H] b_ih + b_hh in (unit, gate) order
+    int n_layers;
+    float *h, *c; size_t layer_stride;            // carried state [layer][tiles * SEQ_TILE][128] (layer_stride floats apart)
+    float *Y; int ldy;                            // last layer's output: f32 rows (tile-major), or
+    unsigned short *Yh, *Yl;                      // its two K-blocked f16 planes of ldy columns (Y == nullptr)
+    int tiles, T, B;
+    // optional head in the same launch (logits != nullptr): n_lin feed-forward layers of 128 units (leaky_relu) as register images
+    // (pack_fc_image), the classifier row and bias; logits / probs at canonical [b][t] (b < B), row stride ld_out
+    const float *lin_w[LSTM_STACK_MAX_LIN], *lin_b[LSTM_STACK_MAX_LIN]; int n_lin;
+    const float *cls_w, *cls_b; float slope;
+    float *logits, *probs; int ld_out;
+    // optional feature stage in the same launch (fb_on): the step's virtual rows (fb.vs_*: chunk + carried tail) are framed and
+    // transformed by the workgroup that consumes them (fbank_pair.h) and `feats` is not read; fb.tab, fb.frame_len, ... as in FbankArgs
+    FbankArgs fb; int fb_on;
+};
+// LDS the feature stage of lstm_stack_kernel needs beside the kernel's static arrays (0 if it cannot run for these arguments)
+size_t lstm_stack_fb_lds_bytes(const FbankArgs &fb, int T);
+bool lstm_stack_supported(int hidden, int dirs, int in_dim, int T, int n_layers);
+hipError_t launch_lstm_stack(const LstmStackArgs &a, hipStream_t s);
+size_t lstm_image_elems(int K);
+void pack_lstm_image(const float *w /*[4 * 128][K], torch row order*/, int K, float *out);
+size_t fc_image_elems();                                                   // a 128 x 128 feed-forward matrix as a register image
+void pack_fc_image(const float *w /*[128][128], torch nn.Linear.weight*/, float *out);
 
 // ---- sincnet.hip: SincNet front end of PyanNet (conv + |.| + maxpool(3) + instance-norm statistics) ----------
 struct SincConvArgs {
