@@ -241,7 +241,7 @@ class VadRuntime:
     def stream_open(self, B: int, chunk: int, graphs: bool = False):
         """Allocate and reset the carried state of B lock-step streams fed `chunk` samples per step.
         graphs: replay each distinct step shape as a hipGraph (see stream_step).  Off by default: a step of a causal 128-unit model
-        is two launches (the feature kernel and lstm_stack_kernel: every layer and the head), 0.061 ms at BASELINE cfg 5 (512 feeds,
+        is one launch (lstm_stack_kernel: feature stage, every layer and the head), 0.059 ms at BASELINE cfg 5 (512 feeds,
         20 ms chunks); a graph has nothing left to shorten (with the 14 per-layer launches of round 2 a replayed step took 0.133 ms
         against 0.125 ms enqueued kernel by kernel)."""
         with torch.cuda.device(self.device):
