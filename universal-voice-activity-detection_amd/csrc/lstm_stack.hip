@@ -13,7 +13,10 @@
 //               phase B: W_hh's image into the same registers; T recurrence steps exactly as lstm_rec_kernel's (h through a
 //                        double-buffered LDS tile, one barrier per step), h_t also written where the next layer reads its input.
 // Exact f32 throughout (the MFMA is a k-ordered fmaf chain); the weights (about 2 MB per workgroup at 4 x 128 units) come from L2.
-// The last layer's h_t leaves as the two K-blocked f16 planes the fused head reads (or f32 rows).
+// The head (feed-forward layers on the same chains, classifier row, sigmoid) and the feature stage (fbank_pair.h: the workgroup frames
+// its 4 rows from the chunk and the carried PCM tail and transforms its <= 8 frame pairs, one per wave) run in the same launch when the
+// model allows: a streaming step is then this one kernel.  Otherwise the features come from fbank_kernel and the last layer's h_t
+// leaves as the two K-blocked f16 planes the fused head reads (or f32 rows).
 #include "uvad_internal.h"
 #include "fbank_pair.h"
 
