@@ -55,7 +55,7 @@ from uvad_amd.pipeline import ForwardPipeline
 m = uvad_amd.PyanNet2(encoding_dim=64); m.build(); seed_weights(m, 1234, 4.0)
 m.attach_fbank(uvad_amd.FbankConfig(num_filters=64, window_type="hamming")); m = m.to(dev).eval()
 pcm = synth_pcm_device(256, 160000, seed=42, device=dev)
-for mode in ("f16p", "f32"):
+for mode in ("f16p", "f16p3", "f32"):
     pipe = ForwardPipeline(m, dev, depth=12, recurrent_tile=16)
     for r in pipe.runtimes: r.set_gemm_mode(mode)
     def run(nsteps):
