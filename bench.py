@@ -24,6 +24,10 @@ Extra objects on the JSON line:
   cpu_baseline -- oracle/torch_ref (torch CPU operators, same op sequence as the reference) timed on
                   this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
   max_abs_logit_err -- GPU logits vs that CPU reference on the sample's first utterances.
+  clocks_during_timed_region -- shader clock and socket power of this GPU (sysfs hwmon, 20 ms samples) inside the timed region: the
+                  in-flight regime runs at the socket's power limit with the clock throttled.
+  exact_f32, three_products, sequential -- the same step in GEMM mode 0 (all-f32 MFMA), in the opt-in mode 3 (three instead of four
+                  f16 products per f32-equivalent product) and submitted strictly one at a time; none of them is the headline value.
 """
 import argparse
 import json
