@@ -128,7 +128,9 @@ int uvad_forward_i16(uvad_ctx *, const int16_t *d_pcm, int B, int64_t S, float *
 
 /* Debug / parity taps: copy of the last LSTM layer output [B][T][hidden*dirs] and of the last
  * feed-forward activation [B][T][lin_hidden] from the most recent uvad_classify on this
- * workspace (async on stream).  Either pointer may be NULL. */
+ * workspace (async on stream).  Either pointer may be NULL.  Where the fused head ran (two 128-unit feed-forward layers, large
+ * launch) the feed-forward tap is recomputed from the LSTM output with the per-layer kernels -- the same bits in GEMM modes 1 / 2;
+ * in mode 3 (three products) no kernel can reproduce the fused head's activation and d_lin_out != NULL returns UVAD_E_UNSUPPORTED. */
 int uvad_get_taps(uvad_ctx *, int B, int T, float *d_lstm_out, float *d_lin_out,
                   const void *d_workspace, void *stream);
 

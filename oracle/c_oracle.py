@@ -85,6 +85,31 @@ def fbank(pcm, cfg, win, mel):
     return out
 
 
+def fbank_f64(pcm, cfg, win, mel, threads=1):
+    """Float64-throughout evaluation of the feature stage on the f32 samples / tables: (B, T, n_mels) float64.
+    threads > 1: one utterance per thread (ctypes releases the GIL)."""
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    B, S = pcm.shape
+    T = num_frames(S, cfg)
+    out = np.empty((B, T, cfg.n_mels), np.float64)
+    win = np.ascontiguousarray(win, np.float32)
+    mel = np.ascontiguousarray(mel, np.float32)
+    fn = lib().orc_fbank_f64
+
+    def one(i):
+        fn(_fp(pcm[i:i + 1]), C.c_int(1), C.c_int64(S), C.byref(cfg), _fp(win), _fp(mel),
+           out[i:i + 1].ctypes.data_as(C.POINTER(C.c_double)))
+
+    if threads > 1 and B > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(int(threads)) as ex:
+            list(ex.map(one, range(B)))
+    else:
+        for i in range(B):
+            one(i)
+    return out
+
+
 def flatten_state_dict(sd, mcfg):
     """torch-keyed dict of numpy arrays -> flat blob in the order orc_classify expects."""
     parts = []

@@ -154,6 +154,50 @@ void orc_fbank(const float *pcm, int B, int64_t S, const orc_fbank_cfg *cfg,
     free(ct); free(st); free(f); free(y); free(pw);
 }
 
+/* The same feature stage in float64 THROUGHOUT (f32 samples, f32 window / mel tables as uploaded to the GPU, every
+ * operation and the output in double): the "truth" the fp32 feature stages -- the HIP kernel and the torch-CPU rfft
+ * restatement alike -- are measured against (tests/test_gpu_scale.py, bench.py).  Same algorithm as orc_fbank above
+ * (SURVEY.md Appendix A), same PARITY UNPINNED status.  pcm [B][S] -> feats [B][T][n_mels] double. */
+void orc_fbank_f64(const float *pcm, int B, int64_t S, const orc_fbank_cfg *cfg,
+                   const float *window, const float *mel, double *feats) {
+    const int L = cfg->frame_len, N = cfg->n_fft, nb = N / 2 + 1, F = cfg->n_mels;
+    const int64_t T = orc_num_frames(S, L, cfg->frame_shift, cfg->snip_edges);
+    const int n_left = cfg->snip_edges ? 0 : (L - cfg->frame_shift) / 2;
+    double *ct = (double *)malloc(sizeof(double) * N), *st = (double *)malloc(sizeof(double) * N);
+    double *f = (double *)malloc(sizeof(double) * L), *y = (double *)malloc(sizeof(double) * L);
+    double *pw = (double *)malloc(sizeof(double) * nb);
+    for (int i = 0; i < N; ++i) { ct[i] = cos(2.0 * M_PI * i / N); st[i] = sin(2.0 * M_PI * i / N); }
+    for (int b = 0; b < B; ++b) {
+        const float *x = pcm + (size_t)b * S;
+        for (int64_t t = 0; t < T; ++t) {
+            int64_t start = t * cfg->frame_shift - n_left;
+            double mu = 0.0;
+            for (int n = 0; n < L; ++n) { f[n] = padded_sample(x, S, start + n); mu += f[n]; }
+            mu = cfg->remove_dc ? mu / L : 0.0;
+            for (int n = 0; n < L; ++n) f[n] -= mu;
+            for (int n = 0; n < L; ++n) y[n] = (f[n] - (double)cfg->preemph * f[n > 0 ? n - 1 : 0]) * (double)window[n];
+            for (int k = 0; k < nb; ++k) {
+                double re = 0.0, im = 0.0;
+                for (int n = 0; n < L; ++n) {
+                    int idx = (int)(((int64_t)k * n) % N);
+                    re += y[n] * ct[idx];
+                    im -= y[n] * st[idx];
+                }
+                pw[k] = re * re + im * im;
+            }
+            double *o = feats + ((size_t)b * T + t) * F;
+            for (int m = 0; m < F; ++m) {
+                double acc = 0.0;
+                const float *w = mel + (size_t)m * nb;
+                for (int k = 0; k < nb; ++k) acc += pw[k] * (double)w[k];
+                if (acc < (double)cfg->log_floor) acc = (double)cfg->log_floor;
+                o[m] = log(acc);
+            }
+        }
+    }
+    free(ct); free(st); free(f); free(y); free(pw);
+}
+
 /* ---------------------------------------------------------------- classifier */
 
 static float sigmoidf_(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }

@@ -76,3 +76,23 @@ def test_shard_indices_partition():
             parts = [shard_indices(n, r, w) for r in range(w)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert [len(p) for p in parts] == [shard_count(n, r, w) for r in range(w)]
+
+
+def test_bench_gpus_n_outside_torchrun_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must start its ranks itself (a child
+    `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 ...` on 127.0.0.1) instead of dying on WORLD_SIZE != --gpus,
+    and relay the children's exit code.  Here there is no GPU, so the ranks stop at "bench.py needs a GPU" -- what is checked is
+    that BOTH ranks were started by the self-launch and that their failure comes back as a non-zero exit code (the successful path,
+    with the JSON line, runs in the -m gpu rehearsal)."""
+    import subprocess, sys
+    if torch.cuda.is_available():
+        pytest.skip("covered by tests/test_gpu_scale.py::test_bench_two_ranks_on_one_gpu_gloo_rehearsal on a GPU box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["UVAD_DIST_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "4"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert "without a torchrun environment" in p.stderr and "--nproc-per-node 2" in p.stderr, p.stderr[-1500:]
+    assert p.stderr.count("bench.py needs a GPU") >= 2, p.stderr[-1500:]          # both ranks ran bench.py's main()
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -3,7 +3,7 @@ vectors produced by the reference's own PyanNet2 class and (b) the CPU oracle on
 
 Tolerances (BASELINE.json north_star: per-frame logits within 1e-4 max-abs of the CPU reference):
   LOGIT_TOL = 1e-4 on logits; probabilities 1e-4; LSTM / feed-forward taps 1e-4;
-  log-mel features 2e-3 absolute in the log domain vs the float64-DFT oracle (the torch-CPU
+  log-mel features 5e-4 absolute in the log domain vs the float64-DFT oracle (the torch-CPU
   rfft restatement itself differs from that oracle by ~1e-4; parity vs lhotse is UNPINNED).
 """
 import numpy as np
@@ -15,7 +15,7 @@ from conftest import GOLDEN_CASES, load_golden
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 1e-4
-FEAT_TOL = 2e-3
+FEAT_TOL = 5e-4
 
 
 def _model(case, sd, dev):
@@ -106,6 +106,36 @@ def test_fbank_matches_oracle(n_mels, window, S):
     err = np.abs(got - want).max()
     print(f"fbank n_mels={n_mels} {window} S={S}: max abs err {err:.2e}")
     assert err < FEAT_TOL
+
+
+@pytest.mark.parametrize("S", [1000, 3999, 4000, 16000 + 57, 24 * 160 * 3 + 1])
+def test_fbank_reads_nothing_outside_its_rows(S):
+    """VERDICT r3 #6 (the two GPU memory-access faults of round 3 came from an ABLATION build whose framing loads had their bounds
+    guard forced on, profiles/README.md): the shipped kernel's 16-byte framing loads are guarded (fbank.hip: `fast = !virt && g >= 0
+    && g + 3 < a.S`, everything else goes through the clamped scalar path).  Checked by value, not by fault: the rows handed to
+    uvad_fbank sit between guard rows inside one allocation, and the output may not depend on what the guard rows hold (NaN / huge
+    values for f32, +-32767 for int16) -- an out-of-row read at a first or last tile would pull them into the edge frames.  Lengths
+    around the 24-frame tile edges and off the 16-byte alignment."""
+    import uvad_amd
+    dev = torch.device("cuda:0")
+    rt = uvad_amd.Fbank(uvad_amd.FbankConfig(num_filters=64, window_type="hamming", device="cuda"))._runtime(dev)
+    g = torch.Generator(device=dev).manual_seed(S)
+    B = 5
+    body = 0.2 * torch.randn(B, S, generator=g, device=dev)
+    outs = []
+    for poison in (float("nan"), 3.0e38, 0.0):
+        buf = torch.full((B + 2, S), poison, device=dev)
+        buf[1:B + 1] = body
+        outs.append(rt.fbank(buf[1:B + 1]))                    # a contiguous view: rows 1..B of the allocation
+        assert torch.isfinite(outs[-1]).all()
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
+    body16 = (body * 32767).clamp(-32767, 32767).to(torch.int16)
+    o16 = []
+    for poison in (32767, -32767, 0):
+        buf = torch.full((B + 2, S), poison, dtype=torch.int16, device=dev)
+        buf[1:B + 1] = body16
+        o16.append(rt.fbank(buf[1:B + 1]))
+    assert torch.equal(o16[0], o16[2]) and torch.equal(o16[1], o16[2])
 
 
 def test_fbank_int16_path_and_edge_cases():
@@ -785,13 +815,25 @@ def test_fbank_random_config_sweep_vs_oracle():
                                    remove_dc_offset=dc, snip_edges=snip, low_freq=low, high_freq=high)
         oc = co.default_fbank_cfg(F, frame_len=L, frame_shift=sh, preemph=pre, remove_dc=int(dc), snip_edges=int(snip), low_hz=low, high_hz=high)
         pcm = tr.synth_pcm(B, S, seed=900 + case)
-        want = co.fbank(pcm, oc, co.window(window, L), co.mel_banks(oc))
+        win, melm = co.window(window, L), co.mel_banks(oc)
+        want = co.fbank(pcm, oc, win, melm)
         rt = uvad_amd.Fbank(cfg)._runtime(dev)
         got = rt.fbank(torch.from_numpy(pcm).to(dev)).cpu().numpy()
         assert got.shape == want.shape, (case, got.shape, want.shape)
         err = float(np.abs(got - want).max()) if want.size else 0.0
         worst = max(worst, err)
-        assert err < FEAT_TOL, (case, dict(flen=flen, fshift=fshift, F=F, window=window, pre=pre, dc=dc, snip=snip, low=low, high=high, B=B, S=S), err)
+        # Off the reference geometry (rectangular windows, no pre-emphasis, 128 narrow bands ...) a weak mel bin can sit 1e-3 of the
+        # frame's energy below f32 resolution for ANY fp32 transform, so the bound follows the classifier's standard: against the
+        # float64-throughout evaluation the kernel may be no further than FEAT_TOL, or than REL x the fp32 torch-CPU rfft path on
+        # the same configuration where that path is itself beyond FEAT_TOL; never beyond the 2e-3 this sweep used to allow.
+        params = dict(flen=flen, fshift=fshift, F=F, window=window, pre=pre, dc=dc, snip=snip, low=low, high=high, B=B, S=S)
+        if want.size:
+            truth = co.fbank_f64(pcm, oc, win, melm, threads=4)
+            cpu = tr.torch_fbank(pcm, torch.from_numpy(win), torch.from_numpy(melm), frame_shift=sh, n_fft=512, preemph=pre, remove_dc=dc,
+                                 snip_edges=snip).numpy()
+            e_gpu, e_cpu = float(np.abs(got - truth).max()), float(np.abs(cpu - truth).max())
+            assert e_gpu < max(FEAT_TOL, 1.5 * e_cpu) and e_gpu < 2e-3, (case, params, e_gpu, e_cpu)
+            assert err < max(FEAT_TOL, 1.5 * e_cpu + 2e-4), (case, params, err, e_cpu)
         if case % 4 == 0:   # int16 ingest of the same signal
             q = np.round(pcm * 32767.0).astype(np.int16)
             want16 = co.fbank(q.astype(np.float32) / 32768.0, oc, co.window(window, L), co.mel_banks(oc))

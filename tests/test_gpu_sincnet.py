@@ -241,6 +241,45 @@ def test_predict_vad_sincnet_intervals_use_receptive_field_geometry(monkeypatch)
         assert [list(x) for x in pp.sincnet_labels_to_intervals(lab, w["duration"])] == w["intervals"]
 
 
+def test_predict_vad_sincnet_two_recordings_keep_their_own_frames(tmp_path, monkeypatch):
+    """two recordings of different length in ONE predict_vad call (SincNet path).  The reference slices its flat row
+    array cumulatively across recordings (predict_sincnet.py:330-336: start_i = sum of the earlier ceil(get_num_frames(.)) + 1),
+    which drifts into the previous recording's padded rows from the second recording on; this build deliberately keeps the first
+    n frames of each recording's OWN rows (scripts.predict_vad).  PARITY UNPINNED against the reference's multi-recording slices by
+    that choice; what is pinned here is the chosen behaviour: a recording's frames, labels and intervals do not depend on which other
+    recordings share the call, and n = ceil(get_num_frames(16000 * duration)) + 1 with the reference's float arithmetic."""
+    import math, wave
+    from config.config import load_config
+    from src.scripts import predict_vad
+    from uvad_amd.sincnet import SincNet
+    from uvad_amd.synth import synth_pcm
+    monkeypatch.setenv("UVAD_FEATURE_EXTRACTOR", "sincnet")
+    lens = {"a.wav": int(12.0 * 16000), "b.wav": 9 * 16000 + 1}
+    for k, (name, n) in enumerate(lens.items()):
+        q = np.round(synth_pcm(1, n, seed=700 + k)[0] * 32767.0).astype("<i2")
+        with wave.open(str(tmp_path / name), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(q.tobytes())
+
+    def run(names):
+        cfg = load_config()
+        cfg.input.kind = "wav"
+        cfg.input.paths = [str(tmp_path / n) for n in names]
+        return {r["recording_id"]: r for r in predict_vad(**cfg)}
+
+    both = run(["a.wav", "b.wav"])
+    for name, n in lens.items():
+        alone = run([name])[name]
+        r = both[name]
+        duration = n / 16000
+        rows = 293 * sum(1 for st in range(0, n, 80000) if min(80000, n - st) > 48000)       # kept 5 s cuts (> 3 s), 293 frames each
+        want = min(int(math.ceil(SincNet.num_frames(16000 * duration))) + 1, rows)
+        assert r["num_frames"] == alone["num_frames"] == want, (name, r["num_frames"], alone["num_frames"], want)
+        assert np.array_equal(r["labels"], alone["labels"]) and np.array_equal(r["probs"], alone["probs"])
+        assert r["intervals"] == alone["intervals"]
+    # 12 s: two full cuts, the 2 s tail dropped -> all 586 rows; 9 s: one full cut + the kept 4 s tail padded to 5 s -> 586 rows, 531 kept
+    assert both["a.wav"]["num_frames"] == 2 * 293 and both["b.wav"]["num_frames"] == SincNet.num_frames(9 * 16000 + 1) + 1 == 531
+
+
 def test_sincnet_random_length_sweep_vs_oracle():
     """Ragged waveform lengths around the tile edges of the three stages (85 / 42 / 42 pooled outputs per tile) and
     batch sizes around the persistent-grid boundaries, against the torch-CPU restatement."""

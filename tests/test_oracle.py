@@ -87,6 +87,11 @@ def test_fbank_restatements_agree(window):
     assert a.shape == b.shape == c.shape == (2, 100, 80)
     assert np.abs(a - c).max() < 2e-4      # C oracle (float frames, double DFT) vs pure float64
     assert np.abs(b - c).max() < 1e-3      # torch fp32 rfft vs float64
+    # the float64-throughout C evaluation (the truth of the full-size feature / end-to-end tests) vs the independent numpy one
+    # (on the configuration's f32 pre-emphasis coefficient, 0.97f, which is what every fp32 implementation is handed)
+    d = co.fbank_f64(pcm, cfg, win, mel, threads=2)
+    c32 = _numpy_fbank_f64(pcm, win.astype(np.float64), mel, preemph=float(np.float32(0.97)))
+    assert d.dtype == np.float64 and np.abs(d - c32).max() < 1e-9
 
 
 def test_oracle_tables_match_product_tables():

@@ -868,7 +868,12 @@ int uvad_get_taps(uvad_ctx *c, int B, int T, float *d_lstm_out, float *d_lin_out
         const bool f16 = c->gemm_mode >= 1 && c->f16_ok;
         if (f16 && mode_fuses_head(c) && head_fused_supported(w.Wd, m.lin_hidden, m.lin_layers, (long long)w.M, c->n_cu)) {
             // the fused head keeps the feed-forward activations on chip: recompute them from the LSTM output planes of the last call
-            // (same kernels, same bits as the unfused path)
+            // with the per-layer kernels -- four products, exact weights: the bits of the fused head in modes 1 / 2.  In mode 3 the
+            // fused head ran THREE products on rounded weights and the per-layer kernels have no such form, so the tap that
+            // produced the logits cannot be reproduced: refuse instead of returning a near-miss.
+            if (mode_products(c) != 4)
+                return fail(c, UVAD_E_UNSUPPORTED, "uvad_get_taps: the feed-forward tap is not available in GEMM mode 3 (fused head, three products); "
+                                                   "pass d_lin_out = NULL or use mode 1");
             int r = feed_forward_layers(c, w, const_cast<char *>(base), B, T, true, (hipStream_t)stream);
             if (r) return r;
         }

@@ -58,6 +58,7 @@ class ForwardPipeline:
         self.streams: Optional[List[torch.cuda.Stream]] = None
         self.streams_tried = 0
         self._k = 0
+        self._active = self.depth
         try:   # every slot holds a weights copy and (later) a workspace: a failure while building slot k must not leave 0..k-1 behind
             for _ in range(self.depth):
                 r = VadRuntime(device=self.device, fbank=model._fbank_cfg, model=cfg)
@@ -93,7 +94,7 @@ class ForwardPipeline:
     def submit(self, pcm: torch.Tensor, want_logits: bool = True, want_probs: bool = False, timed: bool = False) -> Pending:
         """pcm (B, S) f32 on the device, ready on the CURRENT stream.  Returns at once; the step runs on the next slot's stream.
         timed: bracket the step with timing events on its own stream (Pending.elapsed_ms)."""
-        i = self._k % self.depth
+        i = self._k % self._active
         self._k += 1
         s = self.streams[i]
         s.wait_stream(torch.cuda.current_stream(self.device))   # the input was produced on the caller's stream
@@ -109,7 +110,16 @@ class ForwardPipeline:
         return Pending(ev, logits, probs, start)
 
     def slot_of_next_submit(self) -> int:
-        return self._k % self.depth
+        return self._k % self._active
+
+    def set_active_depth(self, n: int):
+        """Submit round-robin to the first n slots only (1 <= n <= depth): fewer steps in flight with the same contexts and
+        streams.  Call between steps (after synchronize())."""
+        n = int(n)
+        if not 1 <= n <= self.depth:
+            raise ValueError(f"active depth {n} outside 1..{self.depth}")
+        self._active = n
+        self._k = 0
 
     def synchronize(self):
         for s in self.streams or []:

@@ -216,14 +216,15 @@ class VadRuntime:
             self._last_bt = (B, T)
             return logits, probs
 
-    def taps(self):
-        """(lstm_out (B,T,H*D), lin_out (B,T,lin_hidden) | None) of the last classify/forward."""
+    def taps(self, lin: bool = True):
+        """(lstm_out (B,T,H*D), lin_out (B,T,lin_hidden) | None) of the last classify/forward.  lin=False: the LSTM tap only (the
+        feed-forward tap is not available in GEMM mode "f16p3" where the fused head ran: include/uvad.h)."""
         with torch.cuda.device(self.device):
             B, T = self._last_bt
             W = self._mc_c.hidden * (2 if self._mc_c.bidirectional else 1)
             y = torch.empty((B, T, W), dtype=torch.float32, device=self.device)
             z = None
-            if self._mc_c.lin_layers > 0:
+            if lin and self._mc_c.lin_layers > 0:
                 z = torch.empty((B, T, self._mc_c.lin_hidden), dtype=torch.float32, device=self.device)
             self._check(self.lib.uvad_get_taps(self.ctx, B, T, y.data_ptr(), z.data_ptr() if z is not None else None,
                                                self._ws.data_ptr(), self._stream()))

@@ -213,10 +213,20 @@ def predict_vad(**kwargs):
         labels = torch.cat(rows_l)
         probs = torch.cat(rows_p)
         duration = len(r["pcm"]) / sr
+        # How many of a recording's frames are kept.  The reference lays the rows of ALL recordings end to end (preds_flat) and
+        # gives recording i the slice [start_i, start_i + n_i) with start_i = the sum of the earlier n_j (predict.py:451-458,
+        # predict_sincnet.py:330-336), n = ceil(duration / frame_shift) + 1 resp. ceil(get_num_frames(16000 * duration)) + 1.  A
+        # recording's rows are whole padded windows, i.e. MORE than n frames (23.7 s -> 5 x 500 = 2500 rows vs n = 2371), so that
+        # cumulative offset drifts: from the second recording on the reference's slice starts inside the previous recording's
+        # rows.  That carry is DELIBERATELY NOT reproduced: every recording here keeps the first n frames of ITS OWN rows (what the
+        # reference computes for the first recording, and for every recording of a one-recording run).  The per-recording
+        # behaviour is pinned by tests (single recordings against the reference-generated fixture, two recordings against their
+        # single-recording runs); parity with the reference's drifting multi-recording slices is unpinned by intent.
         if sincnet:
-            # predict_sincnet.py:331-336: ceil(get_num_frames(16000 * duration)) + 1 frames of the rows laid end to end; :348-370 +
-            # :492-504: frame index -> seconds by receptive field (step 270 samples, offset round(0.5 * 991) = 496), NOT by frame_shift
-            keep = min(SincNet.num_frames(int(round(sr * duration))) + 1, labels.shape[0])
+            # n as the reference computes it: get_num_frames on the FLOAT 16000 * duration (receptive_field.py:28-55 floor-divides
+            # whatever it is given), then ceil + 1; :348-370 + :492-504: frame index -> seconds by receptive field (step 270
+            # samples, offset round(0.5 * 991) = 496), NOT by frame_shift
+            keep = min(int(math.ceil(SincNet.num_frames(16000 * duration))) + 1, labels.shape[0])
             labels, probs = labels[:keep], probs[:keep]
             intervals = sincnet_labels_to_intervals(labels, duration)
         else:

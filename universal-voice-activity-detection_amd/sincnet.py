@@ -81,7 +81,9 @@ class SincNet(nn.Module):
                 "leaky_slope": 0.01, "eps": float(self.norm1d[0].eps)}
 
     @staticmethod
-    def num_frames(num_samples: int, stride: int = 10) -> int:
+    def num_frames(num_samples, stride: int = 10):
+        """Frames of `num_samples` samples (src/utils/receptive_field.py:165-193).  An int gives an int; a float is floor-divided
+        as a float, which is what the reference's predict script does with 16000 * duration (predict_sincnet.py:333)."""
         n = (num_samples - 251) // stride + 1
         for _ in range(2):
             n = n // 3 - 4
