@@ -252,6 +252,21 @@ int uvad_set_gemm_mode(uvad_ctx *, int mode);
  * uvad_get_recurrent_tile returns what the most recent uvad_classify / uvad_forward* call launched (4 or 16; 0 before
  * the first call).  Results agree to rounding between the two (tests/test_gpu_parity.py). */
 int uvad_set_recurrent_tile(uvad_ctx *, int sequences);
+
+/* Time chunks of a layer (the time loop of nn.LSTM and the x_t W_ih^T product in front of it, PyanNet2.py:169-172).  One batch alone
+ * on the GPU cannot overlap its layers (layer l + 1 needs the backward pass of layer l to its last step), but inside a layer the
+ * forward pass at frame t needs the gate rows up to t only and the backward pass those from t on: with n chunks the projection of
+ * chunk i + 1 runs on a stream the library owns, on the CUs the 4-sequence recurrence leaves idle, beside the recurrence of chunk
+ * i on the caller's stream (events fork and join the two; the call stays asynchronous and capturable once the stream pair has been
+ * used outside a capture).  Same kernels and arithmetic per row: outputs are bit-identical to the unchunked call.
+ *   0  (default) automatic: T / 96 chunks, at most 6, of geometrically growing length (only the first one's projection is exposed),
+ *      when the 4-sequence recurrence is the form in use, it leaves at least a quarter of the CUs idle, the GEMM mode is 1 or 3 and
+ *      a side stream concurrent with the caller's was found;
+ *   1  off;   2 .. 64  that many chunks wherever the chunked form can run.
+ * uvad_get_time_chunks: what the most recent uvad_classify / uvad_forward* call ran (1 = not chunked).
+ * Replaces nothing in the reference (its nn.LSTM is one cuDNN / MIOpen call per layer stack). */
+int uvad_set_time_chunks(uvad_ctx *, int chunks);
+int uvad_get_time_chunks(const uvad_ctx *);
 int uvad_get_recurrent_tile(const uvad_ctx *);
 /* What mode 0 would launch for a batch of B sequences (4 or 16).  A sweep sharded over n GPUs that wants every utterance to
  * get the same bits as the unsharded run pins all ranks to uvad_recurrent_tile_for(ctx, GLOBAL batch) (tools/run_cfg4.py

@@ -274,6 +274,65 @@ def test_weight_stationary_projection_is_bit_identical_to_the_streaming_kernel(F
         rt.set_gemm_mode("f16p")
 
 
+@pytest.mark.parametrize("F,lstm,B,T", [(64, None, 256, 1000),                       # cfg 2
+                                        (80, None, 37, 611),                         # K = 96, rows that straddle sequence tiles everywhere
+                                        (64, {"hidden_size": 64}, 61, 509),          # N = 512
+                                        (60, {"bidirectional": False}, 130, 300)])   # one direction
+def test_time_chunked_layers_are_bit_identical_to_one_launch_per_layer(F, lstm, B, T):
+    """uvad_set_time_chunks: a layer cut into n time chunks -- the projection of chunk i + 1 (weight-stationary GEMM over the row tiles
+    that chunk needs first) on the library's side stream beside the 4-sequence recurrence of chunk i (carried state) on the caller's --
+    runs the same kernels with the same arithmetic per row: logits, probabilities and taps equal the unchunked call BIT FOR BIT,
+    for forced chunk counts (also ones that do not divide T), for the automatic choice, run after run, and replayed from a hipGraph."""
+    import uvad_amd
+    from uvad_amd.synth import seed_weights
+    dev = torch.device("cuda:0")
+    m = uvad_amd.PyanNet2(lstm=lstm, encoding_dim=F)
+    m.build()
+    seed_weights(m, 1234, 4.0)
+    m = m.to(dev).eval()
+    rt = m.runtime(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    feats = torch.randn(B, T, F, generator=g, device=dev) * 4.0 - 8.0
+    rt.set_recurrent_tile(4)
+    rt.set_time_chunks(1)
+    want, wantp = (t.clone() for t in rt.classify(feats))
+    assert rt.time_chunks() == 1
+    y_want, z_want = (t.clone() for t in rt.taps())
+    ran = []
+    for n in (0, 2, 3, 7, 8):
+        rt.set_time_chunks(n)
+        for rep in range(2):
+            got, gotp = rt.classify(feats)
+            used = rt.time_chunks()
+            assert torch.equal(got, want) and torch.equal(gotp, wantp), (n, rep, used, float((got - want).abs().max()))
+        y, z = rt.taps()
+        assert torch.equal(y, y_want) and torch.equal(z, z_want), (n, used)
+        ran.append((n, used))
+    print(f"F={F} B={B} T={T}: (requested, used) chunks {ran}")
+    # (a forced count is a ceiling: the library lowers it until every chunk's projection is still a launch the weight-stationary
+    #  kernel takes -- the 61 x 509 case runs unchunked)
+    if B * T >= 128 * 1000:
+        assert dict(ran)[0] > 1 and dict(ran)[8] == 8, "the chunked schedule never ran (no concurrent side stream?)"
+    # captured into a hipGraph on a side stream of the caller's (after an eager call there: the stream pair is probed outside captures)
+    rt.set_time_chunks(4)
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        eager = rt.classify(feats)[0].clone()
+        used_eager = rt.time_chunks()
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            cap, _ = rt.classify(feats)
+        used_cap = rt.time_chunks()
+    cap.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(eager, want) and torch.equal(cap, want), (used_eager, used_cap)
+    rt.set_time_chunks(0)
+    rt.set_recurrent_tile(0)
+
+
 def test_cfg3_feature_loop_hipgraph_4096_streams():
     """BASELINE configs[2]: 4096 streams x 1 s chunks, the per-chunk feature loop (100 uvad_fbank launches) captured in ONE
     hipGraph: replay == eager bit for bit, and a 4-stream subset against the float64-DFT C oracle."""

@@ -74,6 +74,8 @@ SIGNATURES = {
     "uvad_set_gemm_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "uvad_set_recurrent_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "uvad_get_recurrent_tile": (C.c_int, [C.c_void_p]),
+    "uvad_set_time_chunks": (C.c_int, [C.c_void_p, C.c_int]),
+    "uvad_get_time_chunks": (C.c_int, [C.c_void_p]),
     "uvad_recurrent_tile_for": (C.c_int, [C.c_void_p, C.c_int]),
     "uvad_streams_overlap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "uvad_set_timing": (C.c_int, [C.c_void_p, C.c_int]),

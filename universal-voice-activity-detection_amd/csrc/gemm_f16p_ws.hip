@@ -107,6 +107,17 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
 
     // ---- tile queue: row tile m = grp + 8 * c, c drawn from this (group, column tile)'s counter.  Two tiles are known ahead.
     unsigned *ctr = counters + (size_t)(grp * nt + n_tile) * 32;   // one 128-byte line per counter
+    // Which 128-row tiles: all of them (queue index i = row tile i), or the list of this column tile's direction (GemmArgs::ws_tiles: the
+    // time-chunked projections hand each direction the row tiles its recurrence reaches next).  Scalar loads (constant address space):
+    // nothing here may enter the vector-memory counter, whose waits below are counted by hand.
+    typedef const __attribute__((address_space(4))) int *cint_t;
+    cint_t lst = nullptr;
+    if (a.ws_tiles) {
+        const int d = (a.ws_dirs == 2 && n_tile >= nt / 2) ? 1 : 0;
+        lst = (cint_t)(unsigned long long)(a.ws_tiles + a.ws_off[d]);
+        mt = a.ws_len[d];
+    }
+    auto rowtile = [&](int c) { const int i = grp + GROUPS * c; return lst ? lst[i] : i; };
     const int my_tiles = mt > grp ? (mt - grp + GROUPS - 1) / GROUPS : 0;
     if (tid == 0) {
         qword[0] = (int)atomicAdd(ctr, 1u);
@@ -115,6 +126,9 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
     __syncthreads();
     int c_cur = __builtin_amdgcn_readfirstlane(qword[0]), c_nxt = __builtin_amdgcn_readfirstlane(qword[1]);
     if (c_cur >= my_tiles) return;   // nothing left for this workgroup (no DMA issued yet)
+    // the row tiles behind the two queue indices (a queue index past the end reads as the current tile: its DMAs re-read that tile)
+    int r_cur = __builtin_amdgcn_readfirstlane(rowtile(c_cur));
+    int r_nxt = c_nxt < my_tiles ? __builtin_amdgcn_readfirstlane(rowtile(c_nxt)) : r_cur;
 
     // ---- the wave's W fragments for the whole K: lane (fr, fh) holds W[n_tile * 128 + wave * 32 + fr][16 kb + 8 fh .. + 8] of each plane
     static_assert(NPROD == 3 || NPROD == 4, "three or four products");
@@ -143,14 +157,13 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
     const int ra = tid >> 1;
     const unsigned off = (unsigned)((ra * 2 + ((tid & 1) ^ ((ra >> 3) & 1))) * 8);
     const unsigned short *a_hi = a.Ah + off, *a_lo = a.Al + off;
-    auto issue = [&](int stage, int c, int kb) {
-        const size_t t = (size_t)(grp + GROUPS * c) * NKB + kb;   // slab index of (row tile, k-block)
+    auto issue = [&](int stage, int rt, int kb) {
+        const size_t t = (size_t)rt * NKB + kb;   // slab index of (row tile, k-block)
         unsigned short *img = lds + stage * STAGE + wave * 512;
         __builtin_amdgcn_global_load_lds((gptr_t)(a_hi + t * SLAB), (lptr_t)(img), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(a_lo + t * SLAB), (lptr_t)(img + SLAB), 16, 0, 0);
     };
-    // a tile index past the end still gets its DMAs (the vmcnt counts below are static): they re-read the current tile
-    auto clampc = [&](int c, int fallback) { return c < my_tiles ? c : fallback; };
+    // (a queue index past the end still gets its DMAs -- the vmcnt counts below are static --: r_nxt then names the current tile)
 
     // Fragment reads.  Lane (fr, fh) of row block i reads row 32 i + fr, chunk fh ^ ((fr >> 3) & 1): one per-lane base address, the
     // rest is an immediate offset (stage, plane, row block).  They are INLINE ASM with hand-counted lgkmcnt waits: beside LDS-DMA
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
 
     // ---- prologue: k-blocks 0 .. NST-2 of the stream (the current tile, then the next) in flight; k-block 0 in registers
 #pragma unroll
-    for (int v = 0; v < NST - 1; ++v) issue(v, v < NKB ? c_cur : clampc(c_nxt, c_cur), v % NKB);
+    for (int v = 0; v < NST - 1; ++v) issue(v, v < NKB ? r_cur : r_nxt, v % NKB);
     wait_vm<2 * (NST - 2)>();
     __builtin_amdgcn_s_barrier();
     UVAD_WS_READ_FRAGS(0, 0)
@@ -204,8 +217,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
             asm volatile("" : "+a"(w0[kb]), "+a"(w1[kb]));
             if constexpr (NPROD == 4) asm volatile("" : "+a"(w2[kb]));
         }
-        const int c_n = clampc(c_nxt, c_cur);
-        float *gout = a.C + ((size_t)(grp + GROUPS * c_cur) * n64 + g_ntile) * (128 * 64) + g_lane;
+        float *gout = a.C + ((size_t)r_cur * n64 + g_ntile) * (128 * 64) + g_lane;
         unsigned pulled = 0;
         (void)pc; (void)sg_r;   // (named outside inline asm too, so that the generic lambdas below capture them)
         static_for<NKB>([&](auto kb_tag) __attribute__((always_inline)) {
@@ -262,8 +274,8 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
             __builtin_amdgcn_s_barrier();   // ... and everyone's; every wave has k-block kb's fragments in registers, so the slot of kb - 1 is free
             UVAD_WS_SB;
             constexpr int v = kb - 1 + NST;                       // (2) the k-block of the stream that refills that slot
-            const int vc = v < NKB ? c_cur : c_n;
-            const size_t vt = ((size_t)(grp + GROUPS * vc) * NKB + v % NKB) * SLAB;
+            const int vr = v < NKB ? r_cur : r_nxt;
+            const size_t vt = ((size_t)vr * NKB + v % NKB) * SLAB;
             unsigned short *img = lds + ((kb + NST - 1) % NST) * STAGE + wave * 512;
             constexpr int fb = stn * (STAGE * 2);                 // (3) where the fragments of k-block kb + 1 are
             // what goes into gap g (after MFMA pair g)
@@ -329,7 +341,9 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(c_nn) : "v"(q_addr) : "memory");
         gprev = gout;
         c_cur = c_nxt;
+        r_cur = r_nxt;
         c_nxt = __builtin_amdgcn_readfirstlane(c_nn);
+        r_nxt = c_nxt < my_tiles ? __builtin_amdgcn_readfirstlane(rowtile(c_nxt)) : r_cur;
     };
     tile(std::true_type{});
     // (the counter hands every tile index out once, so a workgroup can never run more than my_tiles tiles: the explicit bound is
@@ -360,6 +374,11 @@ bool gemm_f16p_ws_supported(const GemmArgs &a, int n_cu) {
 hipError_t launch_gemm_f16p_ws(const GemmArgs &a, unsigned *counters, int n_cu, hipStream_t s) {
     if (!gemm_f16p_ws_supported(a, n_cu) || !counters || !a.Ah || !a.Al || !a.Wsplit16 || !a.C || a.ldw != a.K) return hipErrorInvalidValue;
     const int mt = (a.M + 127) / 128, nt = a.N / 128;
+    if (a.ws_tiles) {
+        if ((a.ws_dirs != 1 && a.ws_dirs != 2) || (a.ws_dirs == 2 && nt % 2 != 0)) return hipErrorInvalidValue;
+        for (int d = 0; d < a.ws_dirs; ++d)
+            if (a.ws_off[d] < 0 || a.ws_len[d] < 0 || a.ws_len[d] > mt) return hipErrorInvalidValue;
+    }
     hipError_t e = hipMemsetAsync(counters, 0, gemm_f16p_ws_counter_bytes(), s);
     if (e != hipSuccess) return e;
     // one workgroup per CU; every (group, column tile) pair must own at least one workgroup: a multiple of 8 * nt

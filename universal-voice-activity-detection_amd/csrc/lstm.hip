@@ -168,13 +168,13 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
     const unsigned y_lane = (unsigned)(jb * 16 + blk);
     const size_t y_tile = (size_t)(a.ldy / 16) * (PLANE_TILE * 16);   // elements per 128-row tile of a Y plane
 
+    // the steps of this launch: all T frames, or a chunk of them continuing from the carried state (LstmArgs::steps)
+    const int nst = a.steps > 0 ? a.steps : a.T;
+    const int t_lo = a.steps > 0 ? a.t_begin[dir] : 0;
+    auto t_of = [&](int s) { return reverse ? t_lo + nst - 1 - s : t_lo + s; };
     f32x4 gq[PD];
 #pragma unroll
-    for (int p = 0; p < PD; ++p) {
-        const int sp = p < a.T ? p : a.T - 1;
-        const int t = reverse ? a.T - 1 - sp : sp;
-        gq_load(gq[p], g_ptr(t));
-    }
+    for (int p = 0; p < PD; ++p) gq_load(gq[p], g_ptr(t_of(p < nst ? p : nst - 1)));
 
     float hlast = 0.0f;
 
@@ -182,12 +182,12 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
     // gates of step s + PD, so every load lands in the register it is consumed from PD steps later
     // (no register rotation => the compiler can wait with a counted vmcnt instead of vmcnt(0), and
     // the h stores of the last steps stay in flight).
-    for (int s0 = 0; s0 < a.T; s0 += PD) {
+    for (int s0 = 0; s0 < nst; s0 += PD) {
 #pragma unroll
       for (int u = 0; u < PD; ++u) {
         const int s = s0 + u;
-        if (s >= a.T) break;   // wave-uniform
-        const int t = reverse ? a.T - 1 - s : s;
+        if (s >= nst) break;   // wave-uniform
+        const int t = t_of(s);
         // Pin the resident weights in the accumulator half of the unified register file: MFMA reads
         // A operands straight from AGPRs, and VALU-addressable VGPRs stay free for h / gates.
         // (Zero instructions: the constraint only tells the allocator where the values live here.)
@@ -216,9 +216,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
             if (kq == H / 8) {
                 // refill this ring slot with the gates of step min(s + PD, T - 1) (branch-free: a
                 // redundant re-load of the last row is harmless)
-                const int sp = s + PD < a.T ? s + PD : a.T - 1;
-                const int tp = reverse ? a.T - 1 - sp : sp;
-                gq_load(gq[u], g_ptr(tp));
+                gq_load(gq[u], g_ptr(t_of(s + PD < nst ? s + PD : nst - 1)));
             }
         }
         // keep HR LDS reads in flight: [HR reads] then [4 MFMA + 1 read] per group (without this the
@@ -525,6 +523,9 @@ hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
     if (a.tiles <= 0 || a.T <= 0) return hipSuccess;
     const bool can16 = a.H == 128 && a.Whh16h_regs && a.Whh16h_p2 && a.whh16h_scale && !a.h0 && !a.hN;
     if (a.tile_mode == 16 && !can16) return hipErrorInvalidValue;
+    if (a.steps > 0 && (a.tile_mode != 4 || a.t_begin[0] < 0 || a.t_begin[0] + a.steps > a.T ||
+                        (a.dirs > 1 && (a.t_begin[1] < 0 || a.t_begin[1] + a.steps > a.T))))
+        return hipErrorInvalidValue;   // chunks exist for the 4-sequence form only
     const bool planes = a.Y == nullptr;
     if (planes && (!a.Yh || !a.Yl)) return hipErrorInvalidValue;
     const int pick = a.tile_mode ? a.tile_mode : lstm_auto_tile(a.tiles, a.dirs, a.H, a.n_cu);

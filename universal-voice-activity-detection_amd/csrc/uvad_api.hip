@@ -5,11 +5,14 @@
 #include "../../include/uvad.h"
 #include "uvad_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -32,6 +35,15 @@ struct LayerDev {
     float *w_hh16_scale = nullptr;          // [dirs] 2^-S
     bool w_hh16_ok = false;
     int in = 0;
+};
+
+// Row tiles of the tile-major activation matrices (row = (tile * T + t) * 4 + j, 128-row tiles) by the time chunk that needs them first:
+// direction 0 walks t upwards, direction 1 downwards.  list[off[d][i] .. + len[d][i]) = the row tiles of chunk i of direction d.
+struct ChunkPlan {
+    int chunks = 1;
+    std::vector<int> bound;   // chunk i = frames [bound[i], bound[i + 1]) of the forward pass, [T - bound[i + 1], T - bound[i]) of the backward pass
+    int *d_list = nullptr;
+    std::vector<int> off[2], len[2];
 };
 
 struct StreamCounters { int64_t n_samples = 0, n_frames = 0, n_steps = 0; };
@@ -71,6 +83,16 @@ struct uvad_ctx {
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     std::vector<hipEvent_t> layer_ev;
+    // time-chunked layers (uvad_set_time_chunks): the projection of chunk i + 1 on a side stream beside the recurrence of chunk i
+    int chunk_mode = 0;                    // 0 = automatic, 1 = off, n > 1 = n chunks wherever the chunked form can run
+    int chunks_used = 0;                   // chunks of the most recent classify / forward (1 = not chunked)
+    hipStream_t side = nullptr;            // the library's own stream for the chunk projections
+    hipStream_t side_for = nullptr;        // the caller stream `side` was PROVEN concurrent with (nullptr: not yet probed / not concurrent)
+    bool side_probed_for_null = false;     // (a null caller stream is a valid key: remember that it was probed)
+    std::set<hipStream_t> side_failed;     // caller streams no side stream was found concurrent with (not probed again)
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_chunk;
+    std::map<std::tuple<int, int, int, int>, ChunkPlan> chunk_plans;   // (tiles, T, dirs, chunks) -> row-tile lists on the device
 };
 
 namespace {
@@ -104,7 +126,7 @@ int dev_upload(uvad_ctx *c, const T *host, size_t n, T **out, bool weight = fals
 struct WsLayout {
     int tiles = 0, D = 0, Wd = 0, Fp = 0, Zw = 0;
     size_t M = 0;
-    size_t off_G = 0, off_Y[2] = {0, 0}, off_Z[2] = {0, 0}, off_feats = 0, off_fplanes = 0, off_flag = 0, off_ctr = 0, total = 0;
+    size_t off_G = 0, off_Y[2] = {0, 0}, off_Z[2] = {0, 0}, off_feats = 0, off_fplanes = 0, off_flag = 0, off_ctr = 0, off_hc = 0, total = 0;
 };
 // Activation buffers hold EITHER f32 rows OR two f16 planes of the same row width (hi plane, then the lo plane): same bytes.
 WsLayout carve(const uvad_ctx *c, int B, int64_t T) {
@@ -125,6 +147,7 @@ WsLayout carve(const uvad_ctx *c, int B, int64_t T) {
     w.off_fplanes = o; o += align_up(Mp * (size_t)w.Fp * sizeof(float));   // f16 planes of the features (split-f16 GEMM mode)
     w.off_flag = o; o += align_up(sizeof(int));   // device-side "features outside the f16 range" flag (uvad_classify)
     w.off_ctr = o; o += align_up(gemm_f16p_ws_counter_bytes());   // tile-queue counters of the weight-stationary projection kernel
+    w.off_hc = o; o += 2 * align_up((size_t)w.D * w.tiles * SEQ_TILE * m.hidden * sizeof(float));   // (h, c) carried between the time chunks of a layer
     w.total = o;
     return w;
 }
@@ -666,6 +689,119 @@ static bool stream_head_in_stack(const uvad_ctx *c) {
     return true;
 }
 
+// ---- time-chunked layers ---------------------------------------------------------------------------------------------------
+// A batch's recurrence (4-sequence form) occupies tiles x directions CUs and the projection in front of it needs the whole chip for a
+// fraction of that time; layer l + 1 cannot start before layer l has finished (its first frame needs the backward pass's LAST
+// step), so with one launch per stage the projections sit exposed between the recurrences (cfg 2 alone on the GPU: 1.55 of 7.1 ms).
+// Inside ONE layer nothing forces that: the forward pass at frame t needs the gate rows up to t only, the backward pass those from t
+// on.  The layer is therefore cut into time chunks: the projection of chunk i + 1 (weight-stationary GEMM over the row tiles that
+// chunk needs, GemmArgs::ws_tiles) runs on the library's side stream, on the CUs the recurrence leaves idle, while the recurrence of
+// chunk i (LstmArgs::steps, state carried in the workspace) runs on the caller's stream; only the first chunk's projection is exposed.
+// Same kernels, same arithmetic per row: bit-identical outputs (tests/test_gpu_scale.py).
+static int streams_overlap_probe(hipStream_t a, hipStream_t b) {   // 1: kernels on a and b run concurrently, 0: they serialise, < 0: HIP error
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) != hipSuccess) return -1;
+    if (hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(ea); return -1; }
+    int result = -1;
+    do {
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) break;
+        // 3 ms of spinning on a, then an empty spin on b: if b's kernel retires while a's is still running the two
+        // streams sit on different hardware queues; on one queue b waits behind a.
+        if (launch_spin(300000ull, nullptr, a) != hipSuccess || hipEventRecord(ea, a) != hipSuccess) break;
+        if (launch_spin(0ull, nullptr, b) != hipSuccess || hipEventRecord(eb, b) != hipSuccess) break;
+        if (hipEventSynchronize(eb) != hipSuccess) break;
+        const hipError_t q = hipEventQuery(ea);
+        if (q != hipSuccess && q != hipErrorNotReady) break;
+        result = q == hipErrorNotReady ? 1 : 0;
+        if (hipEventSynchronize(ea) != hipSuccess) result = -1;
+    } while (0);
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    return result;
+}
+
+// The side stream, PROVEN concurrent with the caller's stream s (HIP maps streams onto a few hardware queues and two streams on one
+// queue serialise: the chunked schedule would then only add launches).  Probed once per (context, caller stream); never while s is
+// being captured into a graph (the probe synchronises): a capture runs chunked only on a stream that has been used before.
+static bool side_stream_for(uvad_ctx *c, hipStream_t s) {
+    if (c->side && c->side_for == s && (s != nullptr || c->side_probed_for_null)) return true;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+    if (c->side_failed.count(s)) return false;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if (!c->side && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; break; }
+        const int r = streams_overlap_probe(s, c->side);
+        if (r == 1) {
+            c->side_for = s;
+            c->side_probed_for_null = s == nullptr;
+            return true;
+        }
+        (void)hipStreamDestroy(c->side);   // same hardware queue as s (or an error): the next stream created lands on another queue
+        c->side = nullptr;
+        c->side_for = nullptr;
+        c->side_probed_for_null = false;
+        if (r < 0) break;
+    }
+    c->side_failed.insert(s);
+    return false;
+}
+
+static const ChunkPlan *chunk_plan(uvad_ctx *c, int tiles, int T, int D, int chunks, hipStream_t s) {
+    const auto key = std::make_tuple(tiles, T, D, chunks);
+    auto it = c->chunk_plans.find(key);
+    if (it != c->chunk_plans.end()) return &it->second;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;   // (allocates and copies)
+    ChunkPlan P;
+    // Chunk lengths grow geometrically (x 1.3): only chunk 0's projection is exposed, so it is the short one, and projection i + 1 --
+    // on the CUs the recurrence leaves free, about half the chip -- still finishes inside recurrence i (per frame a projection on
+    // half the chip takes ~2/3 of the recurrence's time: the ratio of consecutive lengths has to stay below ~1.5; 1.0 / 1.15 / 1.3 /
+    // 1.4 measured 6.85 / 6.76 / 6.70 / 6.77 ms per cfg-2 step with six chunks, 7.2 unchunked).
+    {
+        std::vector<double> wgt(chunks);
+        double sum = 0.0;
+        for (int i = 0; i < chunks; ++i) sum += (wgt[i] = std::pow(1.3, i));
+        P.bound.assign(1, 0);
+        double acc = 0.0;
+        for (int i = 0; i < chunks; ++i) {
+            acc += wgt[i];
+            const int b = i + 1 == chunks ? T : std::min(T, std::max(P.bound.back() + 1, (int)std::lround(acc / sum * T)));
+            if (b > P.bound.back()) P.bound.push_back(b);
+        }
+        P.bound.back() = T;
+        P.chunks = (int)P.bound.size() - 1;
+    }
+    auto chunk_of = [&](int t) { return (int)(std::upper_bound(P.bound.begin(), P.bound.end(), t) - P.bound.begin()) - 1; };
+    const long rows_per_tile = (long)SEQ_TILE * T, M = (long)tiles * rows_per_tile, mt = (M + 127) / 128;
+    std::vector<std::vector<int>> lists[2];
+    for (int d = 0; d < 2; ++d) lists[d].assign(P.chunks, {});
+    for (long r = 0; r < mt; ++r) {
+        const long first = 128 * r, last = std::min(128 * r + 127, M - 1);
+        int tmin, tmax;
+        if (first / rows_per_tile != last / rows_per_tile) { tmin = 0; tmax = T - 1; }   // the tile spans the end of one sequence tile and the start of the next
+        else { tmin = (int)((first % rows_per_tile) / SEQ_TILE); tmax = (int)((last % rows_per_tile) / SEQ_TILE); }
+        lists[0][chunk_of(tmin)].push_back((int)r);
+        lists[1][chunk_of(T - 1 - tmax)].push_back((int)r);
+    }
+    std::vector<int> flat;
+    for (int d = 0; d < D; ++d)
+        for (int i = 0; i < P.chunks; ++i) {
+            P.off[d].push_back((int)flat.size());
+            P.len[d].push_back((int)lists[d][i].size());
+            flat.insert(flat.end(), lists[d][i].begin(), lists[d][i].end());
+        }
+    if (hipMalloc(reinterpret_cast<void **>(&P.d_list), std::max<size_t>(flat.size(), 1) * sizeof(int)) != hipSuccess) return nullptr;
+    if (hipMemcpy(P.d_list, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(P.d_list); return nullptr; }
+    return &(c->chunk_plans[key] = P);
+}
+
+// How many time chunks a layer of T frames is cut into when nothing is forced: none unless the recurrence leaves at least a quarter
+// of the CUs to the projections; T / 96 chunks, at most 6 (each recurrence launch re-loads its weight image and costs ~10 us).
+static int auto_time_chunks(int T, int tiles, int D, int n_cu) {
+    if ((long)tiles * D * 4 > 3L * n_cu || T < 192) return 1;
+    return std::min(6, T / 96);   // (lengths grow x 1.3 per chunk: six chunks of T = 1000 are 78 ... 290 frames)
+}
+
 // check_range: the features come from the caller (or from a front end with learnable scales) and may lie outside the f16
 // range; the split-f16 layer-0 projection is then replaced by the exact-f32 one ON THE DEVICE (both are enqueued, a flag
 // written by range_flag_kernel lets exactly one of them run), so the call stays asynchronous and capturable.
@@ -725,6 +861,25 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
             return UVAD_OK;
         }
     }
+    // time chunks (see above): only for the 4-sequence recurrence on the weight-stationary split-f16 projections, never for streaming steps
+    int NC = 1;
+    const ChunkPlan *plan = nullptr;
+    if (!ss && !use_stack && f16 && mode_is_ws(c) && c->chunk_mode != 1 && (H == 128 || H == 64) &&
+        (c->rec_tile_mode ? c->rec_tile_mode : lstm_auto_tile(w.tiles, D, H, c->n_cu)) == 4) {
+        int want = c->chunk_mode > 1 ? std::min(c->chunk_mode, T) : auto_time_chunks(T, w.tiles, D, c->n_cu);
+        const long mt = (long)((w.M + 127) / 128);
+        while (want > 1 && (mt / want) * (N4 / 128) < 2L * c->n_cu) --want;   // every chunk must still be a launch the weight-stationary kernel takes
+        if (want > 1 && side_stream_for(c, s) && (plan = chunk_plan(c, w.tiles, T, D, want, s)) != nullptr) {
+            NC = plan->chunks;
+            if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            while ((int)c->ev_chunk.size() < NC) {
+                hipEvent_t e = nullptr;
+                HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                c->ev_chunk.push_back(e);
+            }
+        }
+    }
+    c->chunks_used = NC;
     for (int k = 0; k < (use_stack ? 0 : m.num_layers); ++k) {
         const LayerDev &L = c->layers[k];
         GemmArgs g{};
@@ -742,6 +897,41 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
                 g.Ah = hi_of(w.off_Y[(k - 1) & 1]); g.Al = lo_of(w.off_Y[(k - 1) & 1], w.Wd); g.lda = w.Wd; g.K = w.Wd;
             }
             g.products = mode_products(c);
+            if (NC > 1 && !(k == 0 && check_range) && gemm_f16p_ws_supported(g, c->n_cu)) {
+                // ---- the layer in NC time chunks: every chunk's projection on the side stream (they follow each other there), the
+                //      recurrence of chunk i on s as soon as projection i has finished, state carried through the workspace
+                HIPCHK(c, hipEventRecord(c->ev_fork, s));               // layer k - 1 (or the features) complete
+                HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+                unsigned *ctr = reinterpret_cast<unsigned *>(base + w.off_ctr);
+                // The projection's persistent grid is sized to the CUs the recurrence leaves free: workgroups beyond that would wait in
+                // the dispatcher and take the CUs of a finishing recurrence chunk before the next chunk's workgroups arrive (each holds
+                // its CU for a whole projection chunk: measured, the recurrence then ran 20 % longer and the overlap gained nothing).
+                const int cu_side = std::max(c->n_cu / 4, c->n_cu - w.tiles * D);
+                for (int i = 0; i < NC; ++i) {
+                    GemmArgs gi = g;
+                    gi.ws_tiles = plan->d_list; gi.ws_dirs = D;
+                    for (int d = 0; d < D; ++d) { gi.ws_off[d] = plan->off[d][i]; gi.ws_len[d] = plan->len[d][i]; }
+                    HIPCHK(c, launch_gemm_f16p_ws(gi, ctr, cu_side, c->side));   // (chunk 0 too: on the whole chip it was 0.1 ms shorter and the layer's recurrences 0.3 ms longer)
+                    HIPCHK(c, hipEventRecord(c->ev_chunk[i], c->side));
+                }
+                float *hst = reinterpret_cast<float *>(base + w.off_hc);
+                float *cst = reinterpret_cast<float *>(base + w.off_hc + align_up((size_t)w.D * w.tiles * SEQ_TILE * m.hidden * sizeof(float)));
+                for (int i = 0; i < NC; ++i) {
+                    HIPCHK(c, hipStreamWaitEvent(s, c->ev_chunk[i], 0));
+                    if (i == 0 && c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k + 1], s));   // "projection" = what the recurrence had to wait for
+                    LstmArgs r{};
+                    r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.ldy = w.Wd;
+                    if (y_planes(k)) { r.Yh = hi_of(w.off_Y[k & 1]); r.Yl = lo_of(w.off_Y[k & 1], w.Wd); }
+                    else r.Y = Yf(k & 1);
+                    r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D; r.tile_mode = 4; r.n_cu = c->n_cu; r.products = 4;
+                    r.steps = plan->bound[i + 1] - plan->bound[i];
+                    r.t_begin[0] = plan->bound[i];
+                    r.t_begin[1] = T - plan->bound[i + 1];
+                    r.h0 = i ? hst : nullptr; r.c0 = i ? cst : nullptr; r.hN = hst; r.cN = cst;
+                    HIPCHK(c, launch_lstm(r, s, &c->rec_tile_used));
+                }
+                continue;
+            }
             if (mode_is_ws(c) && gemm_f16p_ws_supported(g, c->n_cu))   // large launches: weights stay in registers, bit-identical gates
                 HIPCHK(c, launch_gemm_f16p_ws(g, reinterpret_cast<unsigned *>(base + w.off_ctr), c->n_cu, s));
             else
@@ -1076,6 +1266,15 @@ int uvad_set_recurrent_tile(uvad_ctx *c, int sequences) {
 
 int uvad_get_recurrent_tile(const uvad_ctx *c) { return c ? c->rec_tile_used : UVAD_E_ARG; }
 
+int uvad_set_time_chunks(uvad_ctx *c, int chunks) {
+    if (!c) return UVAD_E_ARG;
+    if (chunks < 0 || chunks > 64) return fail(c, UVAD_E_ARG, "time chunks must be 0 (automatic), 1 (off) or 2 .. 64");
+    c->chunk_mode = chunks;
+    return UVAD_OK;
+}
+
+int uvad_get_time_chunks(const uvad_ctx *c) { return c ? c->chunks_used : UVAD_E_ARG; }
+
 int uvad_recurrent_tile_for(const uvad_ctx *c, int B) {
     if (!c || !c->has_model || B <= 0) return UVAD_E_ARG;
     return lstm_auto_tile((B + SEQ_TILE - 1) / SEQ_TILE, c->mc.bidirectional ? 2 : 1, c->mc.hidden, c->n_cu);
@@ -1153,6 +1352,11 @@ void uvad_destroy(uvad_ctx *c) {
     for (void *p : c->allocs) (void)hipFree(p);
     for (auto &ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto &kv : c->chunk_plans)
+        if (kv.second.d_list) (void)hipFree(kv.second.d_list);
+    for (auto &ev : c->ev_chunk) (void)hipEventDestroy(ev);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
 }
 

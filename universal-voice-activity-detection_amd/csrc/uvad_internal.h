@@ -67,6 +67,11 @@ struct GemmArgs {
     // sync is needed.
     const int *gate;
     int gate_run_if_set;
+    // gemm_f16p_ws.hip, optional (time-chunked projections, uvad_api.hip): instead of every row tile 0 .. ceil(M / 128) - 1, the column
+    // tiles of direction d (ws_dirs = 2: d = 0 for columns [0, N / 2), d = 1 for the rest; ws_dirs = 1: d = 0 for all) process the
+    // 128-row tiles ws_tiles[ws_off[d] .. ws_off[d] + ws_len[d]) -- device memory, read with scalar loads.  nullptr: all row tiles.
+    const int *ws_tiles;
+    int ws_off[2], ws_len[2], ws_dirs;
 };
 hipError_t launch_gemm(const GemmArgs &a, hipStream_t s);
 int gemm_padded_k(int K);        // gemm.hip: K rounded up to its K-step (weight row padding)
@@ -96,6 +101,10 @@ struct LstmArgs {
     unsigned short *Yh, *Yl;     // the two K-blocked f16 planes (ldy columns) h ~= hi + lo * 2^-11 the f16p GEMM of the next layer reads (Y == nullptr)
     int products;                // 16-sequence form: 4 (0 reads as 4) or 3 (no P2 plane: see GemmArgs)
     int tiles, T, H, dirs;
+    // 4-sequence form, optional: run `steps` time steps only (0 = all T): direction 0 frames t_begin[0] .. t_begin[0] + steps - 1 in
+    // ascending order, direction 1 frames t_begin[1] .. t_begin[1] + steps - 1 in descending order, from / to the carried state
+    // (h0, c0 -> hN, cN).  Rows are addressed with the whole sequence length T.
+    int steps, t_begin[2];
     int tile_mode;               // sequences per workgroup: 0 = by estimated time, 4, 16 (see launch_lstm)
     int n_cu;                    // compute units of the device (0 = 256)
     // optional carried state (streaming): [dirs][tiles*SEQ_TILE][H], nullptr = zeros / discard

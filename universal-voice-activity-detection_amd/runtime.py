@@ -325,6 +325,15 @@ class VadRuntime:
         """What the most recent classify / forward launched (4 or 16)."""
         return int(self.lib.uvad_get_recurrent_tile(self.ctx))
 
+    def set_time_chunks(self, chunks: int):
+        """Time chunks per layer for a batch that runs alone (include/uvad.h): 0 = automatic (default), 1 = off, n = that many.  The
+        projection of chunk i + 1 runs on a stream of the library's own beside the recurrence of chunk i; outputs are bit-identical."""
+        self._check(self.lib.uvad_set_time_chunks(self.ctx, int(chunks)))
+
+    def time_chunks(self) -> int:
+        """What the most recent classify / forward ran (1 = not chunked)."""
+        return int(self.lib.uvad_get_time_chunks(self.ctx))
+
     def der_counts(self, pred: "torch.Tensor", gt: "torch.Tensor") -> "torch.Tensor":
         """pred, gt (B, T) uint8 0/1 on the GPU -> (B, 2) int32 counts {false alarm, missed detection}."""
         with torch.cuda.device(self.device):
