@@ -197,12 +197,13 @@ def main():
     torch.cuda.synchronize(dev)
     udist.barrier()
     t0 = time.perf_counter()
-    recent, all_steps = [], []
+    recent, all_steps, slots = [], [], []
     for k in range(args.steps):
         if k >= n_fly and live_events:   # stage times of the step this context ran last (waits for THAT step only; the other is in flight)
             for name, v in rts[pipe.slot_of_next_submit()].timing_ms().items():
                 acc[name] += v
             n_acc += 1
+        slots.append(pipe.slot_of_next_submit())
         recent.append(submit(k))
         all_steps.append(recent[-1])
         if len(recent) > n_fly:
@@ -219,7 +220,7 @@ def main():
                           "cap and the shader clock is throttled (nominal 2400 MHz: the peaks in `roofline` are quoted at the nominal clock); "
                           "the timed region is entered after `settle.seconds` of the same steps, i.e. at the clock the regime sustains. "
                           "tools/power_probe.py: the same readings for a matrix-pipe-only kernel and for the exact-f32 mode")
-    for i in range(min(n_fly, args.steps) if live_events else 0):
+    for i in (slots[-n_fly:] if live_events else []):   # the slots of the last steps (the settle phase moves the round-robin origin)
         for name, v in rts[i].timing_ms().items():
             acc[name] += v
         n_acc += 1

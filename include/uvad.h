@@ -65,7 +65,9 @@ typedef struct {
  * src/models/segmentation/PyanNet2.py:60-90 (LSTM_DEFAULTS / LINEAR_DEFAULTS / encoding_dim). */
 typedef struct {
     int in_dim;        /* encoding_dim */
-    int hidden;        /* lstm.hidden_size: 128 (64 also implemented) */
+    int hidden;        /* lstm.hidden_size: 128 (and 64) run the register-resident recurrent kernels; any other size with hidden x
+                        * directions a multiple of 32 (<= 1024) runs a generic recurrence (correct to the same bound, slow: W_hh is
+                        * streamed from L2 every step); other sizes: UVAD_E_UNSUPPORTED */
     int num_layers;    /* lstm.num_layers: 4 */
     int bidirectional; /* lstm.bidirectional: 1 */
     int lin_hidden;    /* linear.hidden_size: 128 */

@@ -13,7 +13,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--feeds", type=int, default=512)
 ap.add_argument("--chunk", type=int, default=320)
 ap.add_argument("--seconds", type=float, default=60.0)
+ap.add_argument("--lib", default=None, help="another build of libuvad.so (A/B on one box)")
 args = ap.parse_args()
+if args.lib:
+    from uvad_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(args.lib)
 dev = torch.device("cuda:0")
 m = uvad_amd.PyanNet2(lstm={"bidirectional": False}, encoding_dim=64); m.build(); seed_weights(m, 1234, 4.0)
 m.attach_fbank(uvad_amd.FbankConfig(num_filters=64, window_type="hamming")); m = m.to(dev).eval()
@@ -23,8 +27,9 @@ steps = int(args.seconds * 16000 / C)
 g = torch.Generator(device=dev); g.manual_seed(5)
 audio = 0.1 * torch.randn(B, 64 * C, generator=g, device=dev)        # 64 distinct chunks, cycled
 st = rt.stream_open(B, C)
-lat = []
+lat, dev_ms = [], []
 frames = 0
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for i in range(20):                                                    # warm-up
     rt.stream_step(st, audio[:, (i % 64) * C:(i % 64 + 1) * C].contiguous())
 torch.cuda.synchronize()
@@ -40,8 +45,21 @@ for i in range(steps):
     frames += out.shape[1]
 wall = time.perf_counter() - t_all
 lat = np.array(lat) * 1e3
+# a second, shorter pass with HIP events around the step (kept out of the latency loop: two event records cost the host ~3 us)
+for i in range(min(steps, 300)):
+    x = audio[:, (i % 64) * C:(i % 64 + 1) * C].contiguous()
+    torch.cuda.synchronize()
+    e0.record()
+    rt.stream_step(st, x)
+    e1.record()
+    torch.cuda.synchronize()
+    dev_ms.append(e0.elapsed_time(e1))      # device time between the two event records: the step's kernel plus its launch gap
 audio_s = steps * C / 16000.0
 print(json.dumps({"config": f"{B} feeds x {C}-sample chunks, {audio_s:.0f} s of audio per feed", "steps": steps,
                   "frames_per_feed": frames, "p50_ms": float(np.percentile(lat, 50)), "p99_ms": float(np.percentile(lat, 99)),
                   "max_ms": float(lat.max()), "rtf": float(lat.sum() / 1e3 / audio_s),
+                  "device_ms_p50": float(np.percentile(dev_ms, 50)),
+                  "host_launch_and_sync_ms_p50": float(np.percentile(lat, 50) - np.percentile(dev_ms, 50)),
+                  "what": "p50_ms = host wall time of one step (submit -> synchronised); device_ms = HIP events around the step's one launch (kernel + launch "
+                          "gap on the device); the difference is the host's launch and synchronisation cost",
                   "aggregate_frames_per_s": B * frames / float(lat.sum() / 1e3)}))

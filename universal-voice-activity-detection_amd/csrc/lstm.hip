@@ -432,6 +432,99 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Any other hidden size (the reference constructor takes any, PyanNet2.py:82-95; its configurations use 128): the same recurrence
+// without resident weights.  One workgroup = 4 sequences of one direction; a thread owns hidden units u = tid, tid + 256, ... (H <= 1024:
+// at most 4) for all 4 sequences and, per step, forms their four gate pre-activations as plain f32 fmaf chains over k (the order a
+// torch CPU / the oracle's row dot product has), W_hh rows (torch layout [4H][H]) streamed from L2 every step, h_{t-1} broadcast from
+// LDS.  Slow by design -- the weight matrix crosses the CU once per step -- and exact f32; it exists so that no constructor argument of
+// the reference is refused, the fast forms are the H = 128 / 64 kernels above.
+template <bool PLANES>
+__global__ __launch_bounds__(256) void lstm_rec_any_kernel(LstmArgs a) {
+    constexpr int MAXU = 4;
+    extern __shared__ __attribute__((aligned(16))) float hs[];   // [2][SEQ_TILE][HS]
+    const int H = a.H, HS = H + 4;
+    const int tile = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
+    const bool reverse = dir == 1;
+    const int nseq = a.tiles * SEQ_TILE;
+    const float *W = a.Whh_packed + (size_t)dir * 4 * H * H;     // this form reads the plain torch matrix
+    const int nst = a.steps > 0 ? a.steps : a.T;
+    const int t_lo = a.steps > 0 ? a.t_begin[dir] : 0;
+    float c[MAXU][SEQ_TILE], hl[MAXU][SEQ_TILE];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        const int u = tid + 256 * i;
+#pragma unroll
+        for (int j = 0; j < SEQ_TILE; ++j) {
+            const size_t so = ((size_t)dir * nseq + tile * SEQ_TILE + j) * H + u;
+            c[i][j] = (u < H && a.c0) ? a.c0[so] : 0.0f;
+            hl[i][j] = (u < H && a.h0) ? a.h0[so] : 0.0f;
+            if (u < H) hs[j * HS + u] = hl[i][j];
+        }
+    }
+    __syncthreads();
+    const size_t rowu = (size_t)tile * a.T * SEQ_TILE;
+    for (int s = 0; s < nst; ++s) {
+        const int t = reverse ? t_lo + nst - 1 - s : t_lo + s;
+        const float *hc = hs + (s & 1) * (SEQ_TILE * HS);
+        float *hn = hs + ((s + 1) & 1) * (SEQ_TILE * HS);
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int u = tid + 256 * i;
+            if (u >= H) break;
+            float acc[4][SEQ_TILE];
+#pragma unroll
+            for (int j = 0; j < SEQ_TILE; ++j) {
+                const float4 g = *reinterpret_cast<const float4 *>(a.G + g_index(rowu + (size_t)t * SEQ_TILE + j, dir * 4 * H + u * 4, a.ldg));
+                acc[0][j] = g.x; acc[1][j] = g.y; acc[2][j] = g.z; acc[3][j] = g.w;
+            }
+            for (int k = 0; k < H; k += 4) {
+                float4 w4[4], h4[SEQ_TILE];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) w4[g] = *reinterpret_cast<const float4 *>(W + ((size_t)g * H + u) * H + k);
+#pragma unroll
+                for (int j = 0; j < SEQ_TILE; ++j) h4[j] = *reinterpret_cast<const float4 *>(hc + j * HS + k);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < SEQ_TILE; ++j) {
+                        acc[g][j] = __builtin_fmaf(w4[g].x, h4[j].x, acc[g][j]);
+                        acc[g][j] = __builtin_fmaf(w4[g].y, h4[j].y, acc[g][j]);
+                        acc[g][j] = __builtin_fmaf(w4[g].z, h4[j].z, acc[g][j]);
+                        acc[g][j] = __builtin_fmaf(w4[g].w, h4[j].w, acc[g][j]);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < SEQ_TILE; ++j) {
+                const float h = lstm_cell(f32x4{acc[0][j], acc[1][j], acc[2][j], acc[3][j]}, c[i][j]);
+                hl[i][j] = h;
+                hn[j * HS + u] = h;
+                const size_t row = rowu + (size_t)t * SEQ_TILE + j;
+                if constexpr (PLANES) {
+                    const size_t yo = plane_index(row, dir * H + u, a.ldy);
+                    store_planes(a.Yh + yo, a.Yl + yo, h);
+                } else {
+                    a.Y[row * a.ldy + (size_t)dir * H + u] = h;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (a.hN) {
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int u = tid + 256 * i;
+            if (u >= H) break;
+#pragma unroll
+            for (int j = 0; j < SEQ_TILE; ++j) {
+                const size_t so = ((size_t)dir * nseq + tile * SEQ_TILE + j) * H + u;
+                a.hN[so] = hl[i][j];
+                a.cN[so] = c[i][j];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 constexpr double REC16_ROUND_COST = 1.6;   // time of one round of the 16-sequence form / one round of the 4-sequence form (1.94 vs 1.33 ms per layer at T = 1000; 2.2 ms with every CU busy)
@@ -444,6 +537,10 @@ int lstm_waves(int H) { return H == 128 ? 8 : 4; }
 
 // register image of lstm_rec_kernel: [wave][kq = k/4][lane 64][4 k] with lane = (unit within the wave) * 4 + gate
 void pack_whh(const float *w_hh, int H, float *out) {
+    if (H != 128 && H != 64) {   // lstm_rec_any_kernel reads the torch matrix as it is
+        for (size_t i = 0; i < (size_t)4 * H * H; ++i) out[i] = w_hh[i];
+        return;
+    }
     const int WAVES = lstm_waves(H);
     for (int wave = 0; wave < WAVES; ++wave)
         for (int kq = 0; kq < H / 4; ++kq)
@@ -521,6 +618,19 @@ int lstm_auto_tile(int tiles, int dirs, int H, int n_cu) {
 hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
     if (tile_used) *tile_used = 0;
     if (a.tiles <= 0 || a.T <= 0) return hipSuccess;
+    if (a.H != 128 && a.H != 64) {   // no register-resident form: the generic kernel (plain torch W_hh in Whh_packed)
+        if (a.H < 4 || a.H % 4 || a.H > 1024 || a.tile_mode == 16 || !a.Whh_packed) return hipErrorInvalidValue;
+        if (tile_used) *tile_used = 4;
+        const size_t lds = (size_t)2 * SEQ_TILE * (a.H + 4) * sizeof(float);
+        const dim3 grid(a.tiles, a.dirs);
+        if (a.Y == nullptr) {
+            if (!a.Yh || !a.Yl) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((lstm_rec_any_kernel<true>), grid, dim3(256), lds, s, a);
+        } else {
+            hipLaunchKernelGGL((lstm_rec_any_kernel<false>), grid, dim3(256), lds, s, a);
+        }
+        return hipGetLastError();
+    }
     const bool can16 = a.H == 128 && a.Whh16h_regs && a.Whh16h_p2 && a.whh16h_scale && !a.h0 && !a.hN;
     if (a.tile_mode == 16 && !can16) return hipErrorInvalidValue;
     if (a.steps > 0 && (a.tile_mode != 4 || a.t_begin[0] < 0 || a.t_begin[0] + a.steps > a.T ||

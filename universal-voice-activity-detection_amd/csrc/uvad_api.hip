@@ -263,8 +263,10 @@ int uvad_create(int device, const uvad_fbank_cfg *fb, const uvad_model_cfg *mode
     if (model) {
         c->mc = *model;
         c->has_model = true;
-        if (model->hidden != 128 && model->hidden != 64)
-            return fail(c, UVAD_E_UNSUPPORTED, "lstm hidden_size must be 128 or 64 (register-resident W_hh kernel)");
+        // hidden sizes: 128 and 64 have the register-resident recurrent kernels; any other size whose gate matrix comes in whole
+        // 128-column tiles runs the generic recurrence (lstm_rec_any_kernel: correct, slow)
+        if (model->hidden < 4 || model->hidden > 1024 || (4 * model->hidden * (model->bidirectional ? 2 : 1)) % 128 != 0)
+            return fail(c, UVAD_E_UNSUPPORTED, "lstm hidden_size x directions must be a multiple of 32, hidden_size <= 1024");
         if (model->in_dim < 4 || model->in_dim % 4 != 0)
             return fail(c, UVAD_E_UNSUPPORTED, "encoding_dim must be a positive multiple of 4");
         if (model->num_layers < 1 || model->lin_layers < 0 || (model->lin_layers > 0 && (model->lin_hidden < 4 || model->lin_hidden % 4)))
