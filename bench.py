@@ -379,6 +379,7 @@ def quoted_profile(prefix, batch):
                 if prefix in r["Name"]:
                     got["rocprofv3"] = {"file": f"profiles/{tag}_bench_sequential_kernel_stats.csv", "calls": int(r["Calls"]),
                                         "avg_launch_ms": float(r["AverageNs"]) / 1e6,
+                                        "share_of_all_kernel_time_pct": float(r["Percentage"]),   # the CSV's own column (torch's input-synthesis kernels included)
                                         "share_of_this_librarys_kernel_time_pct": 100.0 * float(r["TotalDurationNs"]) / tot}
                     break
     return got
