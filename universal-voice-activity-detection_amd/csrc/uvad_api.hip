@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <set>
 #include <tuple>
@@ -290,6 +291,52 @@ int uvad_set_tables(uvad_ctx *c, const float *window, const float *mel) {
         st[m] = hi < 0 ? 0 : lo;
         ln[m] = hi < 0 ? 0 : hi - lo + 1;
         if (ln[m] > maxlen) maxlen = ln[m];
+    }
+    // LDS bank spreading of the mel stage.  In fbank_pair() lane m walks its band's power values at scratch index st[m] + i with the SAME
+    // i in every lane, so two lanes of a 32-lane group whose band starts are equal mod 32 hit one bank on every read (the 64-filter
+    // table of the bench: up to 4 lanes per bank in the upper half of the filters -- a third of the kernel's LDS cycles were bank
+    // conflicts).  Every lane runs the same trip count (the longest band, rounded up to a pair), so a shorter band has slack: its start
+    // may be moved down by up to trip - len bins (zero weights in front) without costing an iteration.  A bipartite matching per
+    // 32-lane group (filters -> bank residues, augmenting paths, smallest shift first) picks shifts that make the starts distinct
+    // mod 32 wherever the slack allows; filters it cannot place keep their start.  Same sums up to the order of their terms.
+    {
+        const int trip = 2 * ((maxlen + 1) / 2);
+        for (int g0 = 0; g0 < F; g0 += 32) {   // lanes g0 % 64 .. + 31 of filter pass g0 / 64: one LDS lane group
+            const int n = std::min(32, F - g0);
+            std::vector<int> owner(32, -1), shift_of(n, 0);   // bank residue -> filter of the group; chosen shift per filter
+            // residue reached by filter j with shift sh; candidates in order of increasing shift
+            auto max_shift = [&](int j) { const int m = g0 + j; return ln[m] > 0 ? std::min(trip - ln[m], st[m]) : 0; };
+            std::function<bool(int, std::vector<char> &)> place = [&](int j, std::vector<char> &seen) -> bool {
+                const int m = g0 + j;
+                for (int sh = 0; sh <= max_shift(j); ++sh) {
+                    const int res = ((st[m] - sh) % 32 + 32) % 32;
+                    if (seen[res]) continue;
+                    seen[res] = 1;
+                    if (owner[res] < 0 || place(owner[res], seen)) {
+                        owner[res] = j;
+                        shift_of[j] = sh;
+                        return true;
+                    }
+                }
+                return false;
+            };
+            std::vector<int> order(n);
+            for (int j = 0; j < n; ++j) order[j] = j;
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return max_shift(a) < max_shift(b); });   // the constrained ones first
+            for (int j : order) {
+                std::vector<char> seen(32, 0);
+                if (!place(j, seen)) shift_of[j] = 0;   // no free bank within its slack: stays where it is (conflicts with one other lane)
+            }
+            for (int j = 0; j < n; ++j) {
+                const int m = g0 + j;
+                st[m] -= shift_of[j];
+                ln[m] += ln[m] > 0 ? shift_of[j] : 0;
+            }
+        }
+        // (maxlen is unchanged: every shifted band still fits the trip count)
+        for (int m = 0; m < F; ++m)
+            if (ln[m] > trip) return fail(c, UVAD_E_STATE, "internal: mel band shift exceeded the trip count");
+        maxlen = trip;
     }
     c->mel_stride = maxlen;
     std::vector<float> w((size_t)F * maxlen, 0.0f);
@@ -1286,25 +1333,7 @@ int uvad_streams_overlap(uvad_ctx *c, void *stream_a, void *stream_b) {
     if (!c) return UVAD_E_ARG;
     if (stream_a == stream_b) return 0;
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
-    hipEvent_t ea = nullptr, eb = nullptr;
-    HIPCHK(c, hipEventCreateWithFlags(&ea, hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&eb, hipEventDisableTiming));
-    int result = UVAD_E_HIP;
-    do {
-        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) break;
-        // 3 ms of spinning on a, then an empty spin on b: if b's kernel retires while a's is still running the two
-        // streams sit on different hardware queues; on one queue b waits behind a.
-        if (launch_spin(300000ull, nullptr, a) != hipSuccess || hipEventRecord(ea, a) != hipSuccess) break;
-        if (launch_spin(0ull, nullptr, b) != hipSuccess || hipEventRecord(eb, b) != hipSuccess) break;
-        if (hipEventSynchronize(eb) != hipSuccess) break;
-        const hipError_t q = hipEventQuery(ea);
-        if (q != hipSuccess && q != hipErrorNotReady) break;
-        result = q == hipErrorNotReady ? 1 : 0;
-        if (hipEventSynchronize(ea) != hipSuccess) result = UVAD_E_HIP;
-    } while (0);
-    (void)hipEventDestroy(ea);
-    (void)hipEventDestroy(eb);
+    const int result = streams_overlap_probe((hipStream_t)stream_a, (hipStream_t)stream_b);   // (the probe of the time-chunked layers, above)
     if (result < 0) return fail(c, UVAD_E_HIP, "uvad_streams_overlap: HIP error while probing");
     return result;
 }
