@@ -111,7 +111,13 @@ def test_cfg2_full_size_logit_parity(scale):
             if mode != "f16p3":
                 assert st["p99.9"] < LOGIT_TOL, (mode, tile, "p99.9 vs f64", st["p99.9"])
                 assert st["rms"] < 0.1 * LOGIT_TOL, (mode, tile, "rms vs f64", st["rms"])
-            assert st["max"] < (1.0e-3 if mode == "f16p" else 3.0e-3), (mode, tile, "absolute max vs f64", st["max"])
+            # The single worst of 256 000 frames is the one statistic here that depends on the draw.  This test's input is the feature
+            # kernel's output, and when a change of that kernel (round 4: framing loads) moved the features' last bits, the fp32 CPU
+            # path's OWN worst frame went from 6.4e-4 to 1.14e-3 (default mode: 1.04e-3 with the 4-sequence recurrence, 1.31e-3 with the
+            # 16-sequence one; every bulk statistic below the CPU path's).  The 1e-3 cap the default mode carried since round 2 was a
+            # number fitted to one draw -- the reference arithmetic itself does not meet it on this one -- so the worst frame is now
+            # bounded through the CPU path (<= REL x its worst frame, above) and by the 3e-3 sanity cap the other modes always had.
+            assert st["max"] < 3.0e-3 and st_cpu["max"] < 3.0e-3, (mode, tile, "absolute max vs f64", st["max"], st_cpu["max"])
     rt.set_gemm_mode("f16p")
     rt.set_recurrent_tile(0)
 
@@ -219,6 +225,40 @@ def test_cfg2_end_to_end_pcm_to_logits(scale):
     print("  " + ps.fmt("CPU fp32 vs f64 end-to-end truth", sc))
     for key in ("rms", "mean", "p99.9"):
         assert sg[key] <= REL * sc[key], (key, sg[key], sc[key])
+
+
+@pytest.mark.parametrize("tile", [4, 16])
+def test_large_launch_kernels_reproduce_the_reference_goldens(tile):
+    """the kernels that only run on large launches (gemm_f16p_ws_kernel, head_fused_kernel, lstm_rec16h_kernel with
+    tile 16; with tile 4 the time-chunked layers) never saw the fixtures produced by the reference's own PyanNet2 class, because those are
+    B = 2 batches.  Here the golden input (2 x 1000 x 64) is repeated to B = 256: every copy must reproduce the reference's logits /
+    probabilities / taps within the north-star bound, and all copies must agree bit for bit (batch invariance of the large-launch kernels)."""
+    from conftest import load_golden
+    import uvad_amd
+    g, sd, case = load_golden("pyannet2_f64_T1000")
+    dev = torch.device("cuda:0")
+    m = uvad_amd.PyanNet2(lstm={"num_layers": case["num_layers"], "bidirectional": case["bidirectional"]}, encoding_dim=case["F"])
+    m.build()
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    rt = m.runtime(dev)
+    rt.set_recurrent_tile(tile)
+    rt.set_time_chunks(6 if tile == 4 else 0)
+    x = torch.from_numpy(g["feats"]).to(dev).repeat(128, 1, 1)                 # (256, 1000, 64): copies 2 i, 2 i + 1 of the two golden sequences
+    logits, probs = rt.classify(x)
+    assert rt.recurrent_tile() == tile
+    if tile == 4:
+        assert rt.time_chunks() > 1                                            # the chunked schedule is what ran
+    y, z = rt.taps()
+    want = torch.from_numpy(g["logits"]).to(dev)
+    err = float((logits.view(128, 2, -1) - want).abs().max())
+    perr = float((probs.view(128, 2, -1) - torch.from_numpy(g["probs"]).to(dev)).abs().max())
+    yerr = float((y.view(128, 2, 1000, -1) - torch.from_numpy(g["lstm_out"]).to(dev)).abs().max())
+    zerr = float((z.view(128, 2, 1000, -1) - torch.from_numpy(g["lin_out"]).to(dev)).abs().max())
+    print(f"tile {tile}: 128 copies of the golden batch: logit err {err:.2e} prob {perr:.2e} lstm {yerr:.2e} lin {zerr:.2e}")
+    assert max(err, perr, yerr, zerr) < LOGIT_TOL
+    assert torch.equal(logits.view(128, 2, -1), logits[:2].unsqueeze(0).expand(128, 2, -1).contiguous())
+    rt.set_recurrent_tile(0)
 
 
 @pytest.mark.parametrize("F,lstm,B,T", [(64, None, 256, 1000),                       # cfg 2: K = 64 and K = 256, N = 1024

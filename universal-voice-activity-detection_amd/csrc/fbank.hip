@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
     float *melw = raw + raw_pad;
     float2 *wscr = reinterpret_cast<float2 *>(melw + melw_pad);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
     const int64_t t0 = (int64_t)blockIdx.x * FR_WG;
     const int nfr = (int)((a.T - t0) < FR_WG ? (a.T - t0) : FR_WG);

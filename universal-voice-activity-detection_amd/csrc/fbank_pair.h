@@ -4,6 +4,7 @@
 // sums.  See fbank.hip for the design notes; every LDS access here is a 32-bit operation.
 #pragma once
 #include "uvad_internal.h"
+#include <type_traits>
 
 namespace uvad {
 namespace fbp {
@@ -120,33 +121,70 @@ __device__ __forceinline__ void fbank_pair(const float *xa, const float *xb, boo
     const float2 (&tw2)[8] = kc.tw2;
     const int mst0v = kc.mst0, mst1 = kc.mst1;
         // ---- framing, DC removal, pre-emphasis, window: lane p owns n = p + 64 r ---------------
+        // The frame length L is a launch argument.  Of the eight groups of 64 samples a lane's points come from, L / 64 lie wholly
+        // inside the frame (six at the reference geometry, L = 400), at most one is cut by the frame's end, the rest are empty.  The
+        // loads are instantiated per count of whole groups and selected by one wave-uniform switch: a whole group is read at base +
+        // immediate offsets with no index clamp and no select, only the cut group clamps its index into the frame and zeroes the
+        // samples past it, an empty group loads nothing.  Nothing outside [0, L) of either frame is read.
         float re[8], im[8], pa[8], pbv[8];
+        {
+            const float *va = xa + lane, *vb = xb + lane;
+            const int p0 = lane > 0 ? -1 : 0;   // x[-1] := x[0] (replicate-padded pre-emphasis)
+            auto load = [&](auto whole) {
+                constexpr int NW = decltype(whole)::value;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (r < NW) {
+                        re[r] = va[64 * r];
+                        im[r] = vb[64 * r];
+                        pa[r] = r == 0 ? va[p0] : va[64 * r - 1];
+                        pbv[r] = r == 0 ? vb[p0] : vb[64 * r - 1];
+                    } else if (r == NW) {
+                        const int n = lane + 64 * r;
+                        const bool in = n < L;
+                        const int nc = in ? n : L - 1;
+                        const int np = nc > 0 ? nc - 1 : 0;
+                        const float qa = xa[nc], qb = xb[nc];
+                        re[r] = in ? qa : 0.f;
+                        im[r] = in ? qb : 0.f;
+                        pa[r] = xa[np];
+                        pbv[r] = xb[np];
+                    } else {
+                        re[r] = im[r] = pa[r] = pbv[r] = 0.f;
+                    }
+                }
+            };
+            switch (L >> 6) {   // wave-uniform; 1 <= L <= 512 (uvad_create)
+                case 0: load(std::integral_constant<int, 0>{}); break;
+                case 1: load(std::integral_constant<int, 1>{}); break;
+                case 2: load(std::integral_constant<int, 2>{}); break;
+                case 3: load(std::integral_constant<int, 3>{}); break;
+                case 4: load(std::integral_constant<int, 4>{}); break;
+                case 5: load(std::integral_constant<int, 5>{}); break;
+                case 6: load(std::integral_constant<int, 6>{}); break;
+                case 7: load(std::integral_constant<int, 7>{}); break;
+                default: load(std::integral_constant<int, 8>{}); break;
+            }
+        }
         float suma = 0.f, sumb = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            // unconditional LDS reads (index clamped into the frame); samples past the frame are
-            // zeroed by a select for the mean and by the zero window tap for the spectrum
-            const int n = lane + 64 * r;
-            const bool in = n < L;
-            const int nc = in ? n : L - 1;
-            const int np = nc > 0 ? nc - 1 : 0;
-            const float va = xa[nc], vpa = xa[np], vb = xb[nc], vpb = xb[np];
-            re[r] = in ? va : 0.f;
-            pa[r] = vpa;
-            im[r] = in ? vb : 0.f;
-            pbv[r] = vpb;
             suma += re[r];
             sumb += im[r];
         }
-        float mua = 0.f, mub = 0.f;
+        // (x[n] - mu) - p (x[n-1] - mu) = x[n] - p x[n-1] - (1 - p) mu: the mean enters as one constant per frame.  Without a second
+        // frame xb == xa and the imaginary input is a copy of the real one: finite, and its band energies are never stored.
+        float ca = 0.f, cb = 0.f;
         if (remove_dc) {
-            mua = wave_sum(suma) * inv_len;
-            mub = wave_sum(sumb) * inv_len;
+            const float mua = wave_sum(suma) * inv_len, mub = wave_sum(sumb) * inv_len;
+            ca = __builtin_fmaf(-preemph, mua, mua);
+            cb = __builtin_fmaf(-preemph, mub, mub);
         }
+        (void)has_b;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            re[r] = ((re[r] - mua) - preemph * (pa[r] - mua)) * win[r];
-            im[r] = has_b ? ((im[r] - mub) - preemph * (pbv[r] - mub)) * win[r] : 0.f;
+            re[r] = (__builtin_fmaf(-preemph, pa[r], re[r]) - ca) * win[r];
+            im[r] = (__builtin_fmaf(-preemph, pbv[r], im[r]) - cb) * win[r];
         }
         // ---- pass 1: DFT over n1 (n = 64 n1 + p), twiddle W512^(p k1) ----------------------------
         dft8(re, im);

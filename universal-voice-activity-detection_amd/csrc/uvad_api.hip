@@ -777,20 +777,27 @@ static bool side_stream_for(uvad_ctx *c, hipStream_t s) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
     if (c->side_failed.count(s)) return false;
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        if (!c->side && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { c->side = nullptr; break; }
-        const int r = streams_overlap_probe(s, c->side);
+    // A stream that turns out to share s's hardware queue is kept alive until the search ends: destroyed at once, its queue would be
+    // the least loaded one again and the next stream created would land on it too.
+    std::vector<hipStream_t> same_queue;
+    bool found = false;
+    for (int attempt = 0; attempt < 6 && !found; ++attempt) {
+        hipStream_t cand = c->side;   // first the one proven beside another caller stream, if any
+        c->side = nullptr;
+        if (!cand && hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+        const int r = streams_overlap_probe(s, cand);
         if (r == 1) {
+            c->side = cand;
             c->side_for = s;
             c->side_probed_for_null = s == nullptr;
-            return true;
+            found = true;
+        } else {
+            same_queue.push_back(cand);
+            if (r < 0) break;
         }
-        (void)hipStreamDestroy(c->side);   // same hardware queue as s (or an error): the next stream created lands on another queue
-        c->side = nullptr;
-        c->side_for = nullptr;
-        c->side_probed_for_null = false;
-        if (r < 0) break;
     }
+    for (hipStream_t q : same_queue) (void)hipStreamDestroy(q);
+    if (found) return true;
     c->side_failed.insert(s);
     return false;
 }
