@@ -108,6 +108,27 @@ def test_fbank_matches_oracle(n_mels, window, S):
     assert err < FEAT_TOL
 
 
+def test_fbank_log_of_a_normal_floor_equals_ocml_logf_bit_for_bit():
+    """fbank_pair.h log_floored(): with an energy floor that is a normal float (the reference's is FLT_EPSILON) the kernel takes
+    v_log_f32 + the double-float product with ln 2 without ocml logf's subnormal-argument handling; with a floor below FLT_MIN it
+    calls ocml's logf.  Same PCM through both (floors 1.2e-38 and 1e-39; quiet and loud rows, so that energies span 1e-12 .. 1e+3):
+    every feature must have the same BITS in both -- both floors lie far below every band energy here, so neither clamps."""
+    import uvad_amd
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(11)
+    amp = torch.logspace(-5, 0, 12, device=dev).unsqueeze(1)
+    pcm = amp * torch.randn(12, 16000 + 123, generator=g, device=dev)
+    outs = []
+    for floor in (1.2e-38, 1.0e-39):
+        rt = uvad_amd.Fbank(uvad_amd.FbankConfig(num_filters=80, window_type="povey", energy_floor=floor, device="cuda"))._runtime(dev)
+        outs.append(rt.fbank(pcm))
+        assert torch.isfinite(outs[-1]).all()
+    lo, hi = float(outs[0].min()), float(outs[0].max())
+    print(f"features span [{lo:.1f}, {hi:.1f}] (log of 1.2e-38 = -87.3)")
+    assert lo > -60.0 and hi > 0.0                      # nothing was clamped by either floor
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("S", [1000, 3999, 4000, 16000 + 57, 24 * 160 * 3 + 1])
 def test_fbank_reads_nothing_outside_its_rows(S):
     """VERDICT r3 #6 (the two GPU memory-access faults of round 3 came from an ABLATION build whose framing loads had their bounds

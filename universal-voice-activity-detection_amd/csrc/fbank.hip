@@ -51,13 +51,14 @@ __device__ __forceinline__ float pcm_at(const void *row, int64_t i) {
 }
 
 
-template <bool I16>
+// NORMAL_FLOOR: the energy floor is a normal float (chosen by launch_fbank from FbankArgs::log_floor; see fbp::log_floored)
+template <bool I16, bool NORMAL_FLOOR>
 __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs a, const float2 *__restrict__ tw512) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = a.frame_len, sh = a.frame_shift, F = a.n_mels;
     const int raw_pad = (((FR_WG - 1) * sh + L) + 3) & ~3;
-    const int mel_pairs = (a.tab.mel_stride + 1) / 2;          // bins per filter rounded up to pairs (zero weights in the padding)
-    const int melw_pad = (2 * mel_pairs * F + 3) & ~3;
+    const int mel_quads = a.tab.mel_stride / 4;                // the band loop's trip count: four bins per iteration (zero weights in the padding)
+    const int melw_pad = (int)mel_image_floats(a.tab.mel_stride, F);
     float *raw = smem;
     float *melw = raw + raw_pad;
     float2 *wscr = reinterpret_cast<float2 *>(melw + melw_pad);
@@ -142,8 +143,8 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
             if (i < need) *reinterpret_cast<float4 *>(raw + i) = v[it];   // raw is padded to a multiple of 4
         }
     }
-    // mel weights as [bin-in-band][filter] (transposed and zero-padded to whole pairs on the host), so lane m reads conflict-free
-    for (int i = tid; i < 2 * mel_pairs * F; i += 256) melw[i] = a.tab.mel_wt[i];
+    // mel weights as [bin-in-band][filter] (transposed and zero-padded on the host: mel_image_floats), so lane m reads conflict-free
+    for (int i = tid; i < melw_pad; i += 256) melw[i] = a.tab.mel_wt[i];
 
     // ---- per-lane constants (fbank_pair.h: window taps, twiddles, band starts; retired before the frame loop) ----------------
     fbp::PairConsts kc;
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
     // profiles/r02_concurrency_corruption.json).  It is also 3 % faster.
     float *zr = reinterpret_cast<float *>(wscr + (size_t)wave * (ZB_ELEMS + PB_ELEMS)), *zi = zr + ZB_ELEMS;
     const float inv_len = 1.0f / (float)L;
+    constexpr bool floor_normal = NORMAL_FLOOR;
 
     for (int q = 0; q < PAIRS_PER_WAVE; ++q) {
         const int fa = 2 * (q * 4 + wave);
@@ -167,14 +169,14 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
         const float *xb = raw + (has_b ? fa + 1 : fa) * sh;
 
         // ---- the pair's transform, spectrum split, power and mel band sums (fbank_pair.h); per filter pass every lane gets its two band energies
-        fbp::fbank_pair(xa, xb, has_b, kc, zr, zi, melw, mel_pairs, nfilt_pass, F, L, a.preemph, a.remove_dc != 0, inv_len, lane, [&](int m, float ea, float eb) {
+        fbp::fbank_pair(xa, xb, has_b, kc, zr, zi, melw, mel_quads, nfilt_pass, F, L, a.preemph, a.remove_dc != 0, inv_len, lane, [&](int m, float ea, float eb) {
 
-            // ocml logf (<= 1 ulp), not the 2-ulp-of-log2 __logf: two per lane and frame pair, nothing next to the FFT
+            // (fbp::log_floored: ocml logf's value, without its subnormal-argument handling when the floor rules those out)
             if (a.plane_hi) {
                 // straight into the operand planes of the first projection GEMM (gemm_f16p.hip: x ~= hi + lo * 2^-11, K-blocked, rows in
                 // tile-major order m = (tile * T + t) * 4 + j): the f32 feature tensor never exists.  Columns [F, plane_w) are zero.
                 if (m < a.plane_w) {
-                    const float va = m < F ? logf(fmaxf(ea, a.log_floor)) : 0.f, vb = m < F ? logf(fmaxf(eb, a.log_floor)) : 0.f;
+                    const float va = m < F ? fbp::log_floored(ea, a.log_floor, floor_normal) : 0.f, vb = m < F ? fbp::log_floored(eb, a.log_floor, floor_normal) : 0.f;
                     const size_t row = ((size_t)(b >> 2) * a.T + (size_t)(t0 + fa)) * SEQ_TILE + (b & 3);
                     const size_t oa = plane_index(row, m, a.plane_w);
                     const _Float16 ha = (_Float16)va;
@@ -189,8 +191,8 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
                 }
             } else if (m < F) {
                 float *o = a.feats + ((size_t)b * a.T + t0 + fa) * F + m;
-                o[0] = logf(fmaxf(ea, a.log_floor));
-                if (has_b) o[F] = logf(fmaxf(eb, a.log_floor));
+                o[0] = fbp::log_floored(ea, a.log_floor, floor_normal);
+                if (has_b) o[F] = fbp::log_floored(eb, a.log_floor, floor_normal);
             }
         });
         wave_lds_fence();
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void stream_stage_kernel(const float *chunk_pc
 
 size_t fbank_lds_bytes(const FbankArgs &a) {
     const size_t raw_pad = (size_t)((((FR_WG - 1) * a.frame_shift + a.frame_len) + 3) & ~3);
-    const size_t melw_pad = (size_t)((2 * ((a.tab.mel_stride + 1) / 2) * a.n_mels + 3) & ~3);
+    const size_t melw_pad = mel_image_floats(a.tab.mel_stride, a.n_mels);
     return (raw_pad + melw_pad) * sizeof(float) + 4 * (size_t)(ZB_ELEMS + PB_ELEMS) * sizeof(float2);
 }
 
@@ -244,20 +246,17 @@ hipError_t launch_fbank(const FbankArgs &a, hipStream_t s) {
     if (rows > 65535) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((a.T + FR_WG - 1) / FR_WG), rows);
     const float2 *tw = reinterpret_cast<const float2 *>(a.tab.tw512);
-    hipError_t e;
-    if (a.pcm_is_i16) {
-        if (lds > 48 * 1024) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(fbank_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(fbank_kernel<true>, grid, dim3(256), lds, s, a, tw);
-    } else {
-        if (lds > 48 * 1024) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(fbank_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(fbank_kernel<false>, grid, dim3(256), lds, s, a, tw);
+    const bool normal_floor = a.log_floor >= 1.17549435e-38f;   // FLT_MIN
+    const void *fn = a.pcm_is_i16 ? (normal_floor ? (const void *)fbank_kernel<true, true> : (const void *)fbank_kernel<true, false>)
+                                  : (normal_floor ? (const void *)fbank_kernel<false, true> : (const void *)fbank_kernel<false, false>);
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
     }
+    FbankArgs args = a;
+    void *params[] = {&args, &tw};
+    const hipError_t e = hipLaunchKernel(fn, grid, dim3(256), params, lds, s);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 

@@ -39,6 +39,23 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// log(max(e, floor)) of a band energy.  ocml's logf (<= 1 ulp; the 2-ulp-of-log2 __logf is not used) is v_log_f32 and a
+// double-float product with ln 2 -- and, around it, a rescaling of subnormal arguments (compare, select, ldexp before; select,
+// subtract after) plus two canonicalising v_max in front of the fmaxf.  With a floor that is itself a normal number (the
+// reference's is FLT_EPSILON) the argument is never subnormal: the same four operations on the v_log_f32 result then give ocml's
+// value BIT FOR BIT (tests/test_gpu_parity.py compares the two paths) in 8 instead of 15 vector instructions.  A floor below
+// FLT_MIN takes ocml's logf.
+__device__ __forceinline__ float log_floored(float e, float floor, bool floor_is_normal) {
+    if (!floor_is_normal) return logf(fmaxf(e, floor));
+    float x;
+    asm("v_max_f32 %0, %1, %2" : "=v"(x) : "v"(e), "v"(floor));   // (fmaxf: a NaN energy reads as the floor, as with ocml)
+    const float y = __builtin_amdgcn_logf(x);                     // log2
+    constexpr float C = 0x1.62e42ep-1f, C_LO = 0x1.efa39ep-25f;   // ln 2 = C + C_LO (0x3f317217, 0x3377d1cf)
+    const float t = C * y;
+    const float r = __builtin_fmaf(C, y, __builtin_fmaf(C_LO, y, __builtin_fmaf(y, C, -t)));
+    return __builtin_fabsf(y) < __builtin_inff() ? r : y;
+}
+
 // forward 8-point DFT, in place: out[q] = sum_r in[r] * exp(-2*pi*i*r*q/8)
 __device__ __forceinline__ void dft8(float (&re)[8], float (&im)[8]) {
     constexpr float R = 0.70710678118654752f;
@@ -108,11 +125,11 @@ __device__ __forceinline__ void load_pair_consts(PairConsts &k, const FbankTable
 }
 
 // One frame pair.  xa / xb: the frames' first samples in LDS (xb == xa when there is no second frame); zr / zi: the wave's scratch
-// (ZB_ELEMS floats each); melw: the [bin-in-band][filter] weight image in LDS.  emit(m, ea, eb) is called by every lane once per
+// (ZB_ELEMS floats each, zi == zr + ZB_ELEMS); melw: the [bin-in-band][mel_image_ld(F)] weight image in LDS (mel_image_floats).  emit(m, ea, eb) is called by every lane once per
 // filter pass with its filter index m = lane + 64 * pass (possibly >= F) and the two band energies (before the log).
 template <class Emit>
 __device__ __forceinline__ void fbank_pair(const float *xa, const float *xb, bool has_b, const PairConsts &kc, float *zr, float *zi,
-                                           const float *melw, int mel_pairs, int nfilt_pass, int F, int L, float preemph, bool remove_dc,
+                                           const float *melw, int mel_quads, int nfilt_pass, int F, int L, float preemph, bool remove_dc,
                                            float inv_len, int lane, Emit &&emit) {
 #define ZB_PUT(idx, a, b) { zr[idx] = (a); zi[idx] = (b); }
 #define ZB_GET(idx) make_float2(zr[idx], zi[idx])
@@ -256,28 +273,54 @@ __device__ __forceinline__ void fbank_pair(const float *xa, const float *xb, boo
         }
         wave_lds_fence();
         // ---- mel band sums + log; lane = filter ----------------------------------------------------
-        // Uniform trip count (the longest band, zero-padded weights), two bins per LDS instruction: the weights of bins i, i+1
-        // are F floats apart (ds_read2_b32), their power pairs adjacent (ds_read2_b64, no alignment requirement).  No clamp of
-        // the bin index: a band that runs past bin 256 reads this pair's own spectrum values from the scratch (finite) against
-        // zero weights.
-        for (int ps = 0; ps < nfilt_pass; ++ps) {
-            const int m = lane + 64 * ps;
-            const int mm = m < F ? m : F - 1;
-            const int st = ps == 0 ? mst0v : mst1;   // n_mels <= 128 (checked by uvad_create): no global load in this loop
-            float ea = 0.f, eb = 0.f, ea2 = 0.f, eb2 = 0.f;
-            const float *wp = melw + mm;
-            for (int i = 0; i < mel_pairs; ++i) {
-                const float w0 = wp[(2 * i) * F], w1 = wp[(2 * i + 1) * F];
-                const float2 p0 = ZB_GET(st + 2 * i), p1 = ZB_GET(st + 2 * i + 1);
-                ea = __builtin_fmaf(w0, p0.x, ea);
-                eb = __builtin_fmaf(w0, p0.y, eb);
-                ea2 = __builtin_fmaf(w1, p1.x, ea2);
-                eb2 = __builtin_fmaf(w1, p1.y, eb2);
+        // Uniform trip count (the longest band rounded up to four bins, zero-padded weights), eight bins per iteration (+ one group of
+        // four when the count is odd): their weights are rows of a compile-time stride apart (immediate offsets of ONE lane address),
+        // their power values adjacent, and all twelve reads of an iteration are issued before its first sum -- a wave waits for LDS once
+        // per eight bins of two frames.  (Reading one iteration ahead into a second register set was tried first: hipcc keeps the
+        // loop-carried set in copies, ten v_mov per iteration, and waits for the new loads at the copies.)
+        // No clamp of the bin index: a band that runs past bin 256 reads finite scratch values against zero weights.  Two chains per
+        // frame (even / odd bins), each summed in increasing bin order.
+        auto bands = [&](auto ld_tag) {
+            constexpr int LD = decltype(ld_tag)::value;
+            for (int ps = 0; ps < nfilt_pass; ++ps) {
+                const int m = lane + 64 * ps;
+                const int st = ps == 0 ? mst0v : mst1;   // n_mels <= 128 (checked by uvad_create): no global load in this loop
+                float ea = 0.f, eb = 0.f, ea2 = 0.f, eb2 = 0.f;
+                const float *wp = melw + m;              // (columns [F, LD) of the image are zero)
+                const float *pr = zr + st;
+                float w0[4], a0[4], b0[4], w1[4], a1[4], b1[4];
+#define UVAD_MEL_LOAD(W, A, B, q)                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
+        W[j] = wp[((q) * 4 + j) * LD];                                                                                 \
+        A[j] = pr[(q) * 4 + j];                                                                                        \
+        B[j] = pr[ZB_ELEMS + (q) * 4 + j];   /* zi == zr + ZB_ELEMS: one ds_read2st64_b32 with A[j] */                 \
+    }
+#define UVAD_MEL_SUM(W, A, B)                                                                                          \
+    ea = __builtin_fmaf(W[0], A[0], ea);   eb = __builtin_fmaf(W[0], B[0], eb);                                        \
+    ea2 = __builtin_fmaf(W[1], A[1], ea2); eb2 = __builtin_fmaf(W[1], B[1], eb2);                                      \
+    ea = __builtin_fmaf(W[2], A[2], ea);   eb = __builtin_fmaf(W[2], B[2], eb);                                        \
+    ea2 = __builtin_fmaf(W[3], A[3], ea2); eb2 = __builtin_fmaf(W[3], B[3], eb2);
+                int i = 0;
+                for (; i + 2 <= mel_quads; i += 2) {
+                    UVAD_MEL_LOAD(w0, a0, b0, 0)
+                    UVAD_MEL_LOAD(w1, a1, b1, 1)
+                    UVAD_MEL_SUM(w0, a0, b0)
+                    UVAD_MEL_SUM(w1, a1, b1)
+                    wp += 8 * LD; pr += 8;
+                }
+                if (i < mel_quads) {
+                    UVAD_MEL_LOAD(w0, a0, b0, 0)
+                    UVAD_MEL_SUM(w0, a0, b0)
+                }
+#undef UVAD_MEL_LOAD
+#undef UVAD_MEL_SUM
+                ea += ea2;
+                eb += eb2;
+                emit(m, ea, eb);
             }
-            ea += ea2;
-            eb += eb2;
-            emit(m, ea, eb);
-        }
+        };
+        if (F <= 64) bands(std::integral_constant<int, 64>{});
+        else bands(std::integral_constant<int, 128>{});
 #undef ZB_PUT
 #undef ZB_GET
 }

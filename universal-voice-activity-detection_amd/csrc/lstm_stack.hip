@@ -118,8 +118,8 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_stack_kernel(LstmStackArgs a)
         const FbankArgs &f = a.fb;
         const int L = f.frame_len, sh = f.frame_shift, F = KIN0;
         const int need = (T - 1) * sh + L, raw_ld = (need + 3) & ~3;
-        const int mel_pairs = (f.tab.mel_stride + 1) / 2;
-        float *raw = fbs, *melw = raw + SEQ_TILE * raw_ld, *scr = melw + ((2 * mel_pairs * F + 3) & ~3);
+        const int mel_quads = f.tab.mel_stride / 4, melw_n = (int)mel_image_floats(f.tab.mel_stride, F);
+        float *raw = fbs, *melw = raw + SEQ_TILE * raw_ld, *scr = melw + melw_n;
         auto vs_abs = [&](int b, int p) -> float {   // sample p of row b's [tail | chunk] image (see fbank.hip)
             if (b >= a.B) return 0.0f;
             if (p >= f.vs_tail) return f.vs_chunk[(size_t)b * f.vs_chunk_len + (p - f.vs_tail)];
@@ -137,19 +137,20 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_stack_kernel(LstmStackArgs a)
             const int j = i / f.vs_tail, q = i - j * f.vs_tail, b = tile * SEQ_TILE + j;
             if (b < a.B) f.vs_tail_out[(size_t)b * f.vs_tail + q] = vs_abs(b, f.vs_chunk_len + q);
         }
-        for (int i = tid; i < 2 * mel_pairs * F; i += WAVES * 64) melw[i] = f.tab.mel_wt[i];
+        for (int i = tid; i < melw_n; i += WAVES * 64) melw[i] = f.tab.mel_wt[i];
         fbp::PairConsts kc;
         fbp::load_pair_consts(kc, f.tab, reinterpret_cast<const float2 *>(f.tab.tw512), lane, L, F);
         __syncthreads();
         const int j = wave >> 1, fa = 2 * (wave & 1);
+        const bool floor_normal = f.log_floor >= 1.17549435e-38f;
         if (fa < T) {   // wave-uniform
             const bool has_b = fa + 1 < T;
             float *zr = scr + (size_t)wave * (2 * fbp::ZB_ELEMS), *zi = zr + fbp::ZB_ELEMS;
-            fbp::fbank_pair(raw + j * raw_ld + fa * sh, raw + j * raw_ld + (has_b ? fa + 1 : fa) * sh, has_b, kc, zr, zi, melw, mel_pairs,
+            fbp::fbank_pair(raw + j * raw_ld + fa * sh, raw + j * raw_ld + (has_b ? fa + 1 : fa) * sh, has_b, kc, zr, zi, melw, mel_quads,
                             (F + 63) / 64, F, L, f.preemph, f.remove_dc != 0, 1.0f / (float)L, lane, [&](int m, float ea, float eb) {
                                 if (m < F) {
-                                    xbuf[fa][j][m] = logf(fmaxf(ea, f.log_floor));
-                                    if (has_b) xbuf[fa + 1][j][m] = logf(fmaxf(eb, f.log_floor));
+                                    xbuf[fa][j][m] = fbp::log_floored(ea, f.log_floor, floor_normal);
+                                    if (has_b) xbuf[fa + 1][j][m] = fbp::log_floored(eb, f.log_floor, floor_normal);
                                 }
                             });
         }
@@ -288,7 +289,7 @@ void pack_lstm_image(const float *wm, int K, float *out) {
 size_t lstm_stack_fb_lds_bytes(const FbankArgs &fb, int T) {
     if (!fb.vs_chunk || !fb.tab.mel_wt || !fb.tab.tw512 || T < 1 || T > LSTM_STACK_TMAX || fb.n_mels > 128) return 0;
     const size_t need = (size_t)(T - 1) * fb.frame_shift + fb.frame_len, raw_ld = (need + 3) & ~(size_t)3;
-    const size_t melw = (size_t)((2 * ((fb.tab.mel_stride + 1) / 2) * fb.n_mels + 3) & ~3);
+    const size_t melw = mel_image_floats(fb.tab.mel_stride, fb.n_mels);
     const size_t bytes = (SEQ_TILE * raw_ld + melw + (size_t)WAVES * 2 * fbp::ZB_ELEMS) * sizeof(float);
     return bytes <= 120 * 1024 ? bytes : 0;
 }

@@ -295,12 +295,12 @@ int uvad_set_tables(uvad_ctx *c, const float *window, const float *mel) {
     // LDS bank spreading of the mel stage.  In fbank_pair() lane m walks its band's power values at scratch index st[m] + i with the SAME
     // i in every lane, so two lanes of a 32-lane group whose band starts are equal mod 32 hit one bank on every read (the 64-filter
     // table of the bench: up to 4 lanes per bank in the upper half of the filters -- a third of the kernel's LDS cycles were bank
-    // conflicts).  Every lane runs the same trip count (the longest band, rounded up to a pair), so a shorter band has slack: its start
+    // conflicts).  Every lane runs the same trip count (the longest band, rounded up to four bins), so a shorter band has slack: its start
     // may be moved down by up to trip - len bins (zero weights in front) without costing an iteration.  A bipartite matching per
     // 32-lane group (filters -> bank residues, augmenting paths, smallest shift first) picks shifts that make the starts distinct
     // mod 32 wherever the slack allows; filters it cannot place keep their start.  Same sums up to the order of their terms.
     {
-        const int trip = 2 * ((maxlen + 1) / 2);
+        const int trip = 4 * ((maxlen + 3) / 4);
         for (int g0 = 0; g0 < F; g0 += 32) {   // lanes g0 % 64 .. + 31 of filter pass g0 / 64: one LDS lane group
             const int n = std::min(32, F - g0);
             std::vector<int> owner(32, -1), shift_of(n, 0);   // bank residue -> filter of the group; chosen shift per filter
@@ -347,10 +347,10 @@ int uvad_set_tables(uvad_ctx *c, const float *window, const float *mel) {
     if ((r = dev_upload(c, st.data(), st.size(), &c->d_mel_start))) return r;
     if ((r = dev_upload(c, ln.data(), ln.size(), &c->d_mel_len))) return r;
     if ((r = dev_upload(c, w.data(), w.size(), &c->d_mel_w))) return r;
-    const int rows_t = 2 * ((maxlen + 1) / 2);
-    std::vector<float> wt((size_t)rows_t * F, 0.0f);
+    const int ld_t = mel_image_ld(F);
+    std::vector<float> wt(mel_image_floats(maxlen, F), 0.0f);
     for (int m = 0; m < F; ++m)
-        for (int i = 0; i < ln[m]; ++i) wt[(size_t)i * F + m] = w[(size_t)m * maxlen + i];
+        for (int i = 0; i < ln[m]; ++i) wt[(size_t)i * ld_t + m] = w[(size_t)m * maxlen + i];
     if ((r = dev_upload(c, wt.data(), wt.size(), &c->d_mel_wt))) return r;
     c->tables_set = true;
     return UVAD_OK;

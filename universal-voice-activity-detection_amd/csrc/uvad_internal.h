@@ -165,10 +165,14 @@ struct FbankTables {            // device pointers owned by the ctx
     const int *mel_start;       // [n_mels] first bin with non-zero weight
     const int *mel_len;         // [n_mels] number of bins
     const float *mel_w;         // [n_mels][mel_stride] weights (zero padded)
-    const float *mel_wt;        // the same transposed: [2 * ceil(mel_stride / 2)][n_mels] (zero padded), the LDS image of fbank_kernel
-    int mel_stride;             // max band length rounded up
+    const float *mel_wt;        // the same transposed, the LDS image of the mel stage: [mel_stride][mel_image_ld(n_mels)] (zero padded)
+    int mel_stride;             // the uniform trip count of the band loop: the longest band rounded up to a multiple of 4 bins
     const float *tw512;         // [512][2] (cos, -sin)(2*pi*j/512): forward FFT twiddles
 };
+// The mel stage's weight image (fbank_pair.h): one row of mel_image_ld floats per bin-in-band, a compile-time row stride in the kernels
+// (the weights a lane needs per iteration sit at immediate offsets).
+__host__ __device__ inline int mel_image_ld(int n_mels) { return n_mels <= 64 ? 64 : 128; }
+__host__ __device__ inline size_t mel_image_floats(int mel_stride, int n_mels) { return (size_t)mel_stride * mel_image_ld(n_mels); }
 struct FbankArgs {
     const void *pcm; int pcm_is_i16;
     int B; int64_t S; int64_t T;
