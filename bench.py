@@ -331,9 +331,9 @@ def main():
 def kernel_names(rec_tile, products=4, gemm_mode="f16p"):
     """The kernel instances a cfg-2 step launches (as rocprofv3 prints them, profiles/*_kernel_stats.csv), derived from the mode."""
     if gemm_mode == "f32":
-        return {"fbank": "fbank_kernel<false> (f32 PCM)", "proj": "gemm_f32_kernel", "head": "gemm_f32_kernel + classifier_kernel",
+        return {"fbank": "fbank_kernel<false, true> (f32 PCM, normal energy floor)", "proj": "gemm_f32_kernel", "head": "gemm_f32_kernel + classifier_kernel",
                 "recurrent": f"lstm_rec16h_kernel<false, {products}>" if rec_tile == 16 else "lstm_rec_kernel<128, 8, false>"}
-    return {"fbank": "fbank_kernel<false> (f32 PCM)", "proj": f"gemm_f16p_ws_kernel<16, {products}> (K = 256; <4, {products}> at K = 64)",
+    return {"fbank": "fbank_kernel<false, true> (f32 PCM, normal energy floor)", "proj": f"gemm_f16p_ws_kernel<16, {products}> (K = 256; <4, {products}> at K = 64)",
             "head": f"head_fused_kernel<8, {products}>",
             "recurrent": f"lstm_rec16h_kernel<true, {products}>" if rec_tile == 16 else "lstm_rec_kernel<128, 8, true>"}
 
