@@ -108,6 +108,45 @@ def test_fbank_matches_oracle(n_mels, window, S):
     assert err < FEAT_TOL
 
 
+@pytest.mark.parametrize("F", [40, 64, 80])
+def test_fbank_arbitrary_mel_matrix_with_weight_on_the_last_bin(F):
+    """uvad_set_tables takes ANY (n_mels, 257) matrix.  The kaldi-style tables of the reference carry a zero column at bin 256 and the
+    kernel then skips that bin's power (FbankTables::nyquist); a matrix that does weigh it -- here random non-negative bands of random
+    width, some reaching bin 256, one filter made of bins 255 and 256 only -- must take the other path and still match the float64
+    oracle on the same table.  Also covers band lengths / starts the bank-spreading shift of the mel stage has not seen in the other tests."""
+    import uvad_amd
+    from oracle import c_oracle as co, torch_ref as tr
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1000 + F)
+    mel = np.zeros((F, 257), np.float32)
+    for m in range(F):
+        width = int(rng.integers(1, 30))
+        lo = int(rng.integers(0, 257 - width + 1)) if m % 5 else 257 - width     # every fifth band ends at bin 256
+        mel[m, lo:lo + width] = rng.uniform(0.05, 1.0, width).astype(np.float32)
+    mel[F - 1] = 0.0
+    mel[F - 1, 255:257] = (0.5, 1.0)
+    oc = co.default_fbank_cfg(F)
+    win = co.window("povey", 400)
+    pcm = tr.synth_pcm(3, 16000 + 77, seed=31)
+    rt = uvad_amd.Fbank(uvad_amd.FbankConfig(num_filters=F, window_type="povey", device="cuda"))._runtime(dev)
+    rt.set_tables(win, mel)
+    got = rt.fbank(torch.from_numpy(pcm).to(dev)).cpu().numpy()
+    truth = co.fbank_f64(pcm, oc, win, mel)
+    cpu = tr.torch_fbank(pcm, torch.from_numpy(win), torch.from_numpy(mel), frame_shift=160, n_fft=512, preemph=0.97, remove_dc=True, snip_edges=False).numpy()
+    e_gpu, e_cpu = float(np.abs(got - truth).max()), float(np.abs(cpu - truth).max())
+    print(f"F={F}: arbitrary mel matrix, bin 256 weighted: max err vs f64 GPU {e_gpu:.2e}, torch-CPU {e_cpu:.2e}")
+    assert e_gpu < max(FEAT_TOL, 2.0 * e_cpu)
+    # the same matrix with the last column cleared takes the skipping path: the filters that never touched bin 256 keep their bits
+    mel0 = mel.copy()
+    mel0[:, 256] = 0.0
+    rt.set_tables(win, mel0)
+    got0 = rt.fbank(torch.from_numpy(pcm).to(dev)).cpu().numpy()
+    untouched = np.nonzero(mel[:, 256] == 0.0)[0]
+    assert len(untouched) > F // 2
+    assert np.abs(got0[..., untouched] - truth[..., untouched]).max() < max(FEAT_TOL, 2.0 * e_cpu)
+    rt.set_tables(win, co.mel_banks(oc))
+
+
 def test_fbank_log_of_a_normal_floor_equals_ocml_logf_bit_for_bit():
     """fbank_pair.h log_floored(): with an energy floor that is a normal float (the reference's is FLT_EPSILON) the kernel takes
     v_log_f32 + the double-float product with ln 2 without ocml logf's subnormal-argument handling; with a floor below FLT_MIN it

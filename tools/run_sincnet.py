@@ -17,6 +17,7 @@ ap.add_argument("--check", type=int, default=4, help="utterances compared with t
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 B, S = args.batch, int(args.seconds * 16000)
+torch.manual_seed(1234)   # the SincNet convolutions keep torch's default initialisation: seeded, so that two runs time and check the same network
 m = uvad_amd.PyanNet()
 m.build()
 seed_weights(m, 1234, 4.0)   # classifier only; the SincNet front end keeps its mel-spaced initialisation

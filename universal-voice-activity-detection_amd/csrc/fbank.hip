@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
         const float *xb = raw + (has_b ? fa + 1 : fa) * sh;
 
         // ---- the pair's transform, spectrum split, power and mel band sums (fbank_pair.h); per filter pass every lane gets its two band energies
-        fbp::fbank_pair(xa, xb, has_b, kc, zr, zi, melw, mel_quads, nfilt_pass, F, L, a.preemph, a.remove_dc != 0, inv_len, lane, [&](int m, float ea, float eb) {
+        fbp::fbank_pair(xa, xb, has_b, kc, zr, zi, melw, mel_quads, a.tab.nyquist != 0, nfilt_pass, F, L, a.preemph, a.remove_dc != 0, inv_len, lane, [&](int m, float ea, float eb) {
 
             // (fbp::log_floored: ocml logf's value, without its subnormal-argument handling when the floor rules those out)
             if (a.plane_hi) {

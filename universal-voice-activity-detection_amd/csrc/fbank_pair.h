@@ -129,7 +129,7 @@ __device__ __forceinline__ void load_pair_consts(PairConsts &k, const FbankTable
 // filter pass with its filter index m = lane + 64 * pass (possibly >= F) and the two band energies (before the log).
 template <class Emit>
 __device__ __forceinline__ void fbank_pair(const float *xa, const float *xb, bool has_b, const PairConsts &kc, float *zr, float *zi,
-                                           const float *melw, int mel_quads, int nfilt_pass, int F, int L, float preemph, bool remove_dc,
+                                           const float *melw, int mel_quads, bool nyquist, int nfilt_pass, int F, int L, float preemph, bool remove_dc,
                                            float inv_len, int lane, Emit &&emit) {
 #define ZB_PUT(idx, a, b) { zr[idx] = (a); zi[idx] = (b); }
 #define ZB_GET(idx) make_float2(zr[idx], zi[idx])
@@ -253,23 +253,25 @@ __device__ __forceinline__ void fbank_pair(const float *xa, const float *xb, boo
         }
         wave_lds_fence();
         // ---- split the two real spectra, power: A = (Z[k] + conj Z[N-k])/2, B = (Z[k] - conj Z[N-k])/(2i)
-        // (all reads first, then the power pairs overwrite the scratch)
+        // (all reads first, then the power pairs overwrite the scratch).  Bins 0 .. 255 are four rounds of 64 lanes; bin 256 is a fifth
+        // round for lane 0's sake, run only if some filter weighs it (FbankTables::nyquist; otherwise slot 256 keeps a finite spectrum
+        // value, which the band loop may read against a zero weight).
         {
             float2 pw[5];
-#pragma unroll
-            for (int d = 0; d < 5; ++d) {
-                const int k = lane + 64 * d;
-                const int kc = d < 4 ? k : (lane == 0 ? 256 : 0);
+            auto power = [&](int kc) {
                 const float2 z = ZB_GET(kc);
                 const float2 w = ZB_GET((NFFT - kc) & (NFFT - 1));
                 const float ar = z.x + w.x, ai = z.y - w.y;
                 const float br = z.y + w.y, bi = z.x - w.x;
-                pw[d] = make_float2(0.25f * (ar * ar + ai * ai), 0.25f * (br * br + bi * bi));
-            }
+                return make_float2(0.25f * (ar * ar + ai * ai), 0.25f * (br * br + bi * bi));
+            };
+#pragma unroll
+            for (int d = 0; d < 4; ++d) pw[d] = power(lane + 64 * d);
+            if (nyquist) pw[4] = power(lane == 0 ? 256 : 0);   // wave-uniform branch
             wave_lds_fence();
 #pragma unroll
-            for (int d = 0; d < 5; ++d)
-                if (d < 4 || lane == 0) ZB_PUT(lane + 64 * d, pw[d].x, pw[d].y);
+            for (int d = 0; d < 4; ++d) ZB_PUT(lane + 64 * d, pw[d].x, pw[d].y);
+            if (nyquist && lane == 0) ZB_PUT(256, pw[4].x, pw[4].y);
         }
         wave_lds_fence();
         // ---- mel band sums + log; lane = filter ----------------------------------------------------

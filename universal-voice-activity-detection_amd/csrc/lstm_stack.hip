@@ -146,7 +146,7 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_stack_kernel(LstmStackArgs a)
         if (fa < T) {   // wave-uniform
             const bool has_b = fa + 1 < T;
             float *zr = scr + (size_t)wave * (2 * fbp::ZB_ELEMS), *zi = zr + fbp::ZB_ELEMS;
-            fbp::fbank_pair(raw + j * raw_ld + fa * sh, raw + j * raw_ld + (has_b ? fa + 1 : fa) * sh, has_b, kc, zr, zi, melw, mel_quads,
+            fbp::fbank_pair(raw + j * raw_ld + fa * sh, raw + j * raw_ld + (has_b ? fa + 1 : fa) * sh, has_b, kc, zr, zi, melw, mel_quads, f.tab.nyquist != 0,
                             (F + 63) / 64, F, L, f.preemph, f.remove_dc != 0, 1.0f / (float)L, lane, [&](int m, float ea, float eb) {
                                 if (m < F) {
                                     xbuf[fa][j][m] = fbp::log_floored(ea, f.log_floor, floor_normal);

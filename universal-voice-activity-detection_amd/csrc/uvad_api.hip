@@ -61,7 +61,7 @@ struct uvad_ctx {
     // device
     float *d_window = nullptr, *d_mel_w = nullptr, *d_mel_wt = nullptr, *d_tw512 = nullptr;
     int *d_mel_start = nullptr, *d_mel_len = nullptr;
-    int mel_stride = 0;
+    int mel_stride = 0, mel_nyquist = 1;
     std::vector<LayerDev> layers;
     std::vector<float *> lin_w, lin_b;
     std::vector<unsigned short *> lin_w_split16;
@@ -339,6 +339,9 @@ int uvad_set_tables(uvad_ctx *c, const float *window, const float *mel) {
         maxlen = trip;
     }
     c->mel_stride = maxlen;
+    c->mel_nyquist = 0;
+    for (int m = 0; m < F; ++m)
+        if (mel[(size_t)m * nb + nb - 1] != 0.0f) c->mel_nyquist = 1;
     std::vector<float> w((size_t)F * maxlen, 0.0f);
     for (int m = 0; m < F; ++m)
         for (int i = 0; i < ln[m]; ++i) w[(size_t)m * maxlen + i] = mel[(size_t)m * nb + st[m] + i];
@@ -671,7 +674,7 @@ static int fbank_impl(uvad_ctx *c, const void *d_pcm, int is_i16, int B, int64_t
     a.preemph = c->fb.preemph; a.log_floor = c->fb.log_floor; a.remove_dc = c->fb.remove_dc; a.snip_edges = c->fb.snip_edges;
     a.feats = d_feats; a.plane_hi = plane_hi; a.plane_lo = plane_lo; a.plane_w = plane_w;
     a.tab.window = c->d_window; a.tab.mel_start = c->d_mel_start; a.tab.mel_len = c->d_mel_len;
-    a.tab.mel_w = c->d_mel_w; a.tab.mel_wt = c->d_mel_wt; a.tab.mel_stride = c->mel_stride; a.tab.tw512 = c->d_tw512;
+    a.tab.mel_w = c->d_mel_w; a.tab.mel_wt = c->d_mel_wt; a.tab.mel_stride = c->mel_stride; a.tab.tw512 = c->d_tw512; a.tab.nyquist = c->mel_nyquist;
     HIPCHK(c, launch_fbank(a, (hipStream_t)stream));
     return UVAD_OK;
 }
@@ -1247,7 +1250,7 @@ int uvad_stream_step(uvad_ctx *c, const float *d_pcm_chunk, int B, int chunk, vo
         fa.plane_w = w.Fp;
     }
     fa.tab.window = c->d_window; fa.tab.mel_start = c->d_mel_start; fa.tab.mel_len = c->d_mel_len;
-    fa.tab.mel_w = c->d_mel_w; fa.tab.mel_wt = c->d_mel_wt; fa.tab.mel_stride = c->mel_stride; fa.tab.tw512 = c->d_tw512;
+    fa.tab.mel_w = c->d_mel_w; fa.tab.mel_wt = c->d_mel_wt; fa.tab.mel_stride = c->mel_stride; fa.tab.tw512 = c->d_tw512; fa.tab.nyquist = c->mel_nyquist;
     // One launch for the whole step when the stack kernel also takes the head and the feature stage fits beside it (lstm_stack.hip)
     const bool fuse_fb = !planes && stream_uses_stack(c, k) && stream_head_in_stack(c) && lstm_stack_fb_lds_bytes(fa, k) > 0;
     if (!fuse_fb) HIPCHK(c, launch_fbank(fa, s));

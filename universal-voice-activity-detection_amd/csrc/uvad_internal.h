@@ -168,6 +168,8 @@ struct FbankTables {            // device pointers owned by the ctx
     const float *mel_wt;        // the same transposed, the LDS image of the mel stage: [mel_stride][mel_image_ld(n_mels)] (zero padded)
     int mel_stride;             // the uniform trip count of the band loop: the longest band rounded up to a multiple of 4 bins
     const float *tw512;         // [512][2] (cos, -sin)(2*pi*j/512): forward FFT twiddles
+    int nyquist;                // 1 if any filter weighs bin n_fft / 2 (kaldi-style tables, the reference's, carry a zero column there: the
+                                // power of that bin -- a fifth round of the spectrum split for one lane's sake -- is then not computed)
 };
 // The mel stage's weight image (fbank_pair.h): one row of mel_image_ld floats per bin-in-band, a compile-time row stride in the kernels
 // (the weights a lane needs per iteration sit at immediate offsets).
