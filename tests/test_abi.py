@@ -112,6 +112,9 @@ def test_feature_kernel_has_no_64_bit_lds_operations():
     wide = sorted({op for op in lds if re.search(r"_b64$|_b96$", op)})
     assert not wide, f"64/96-bit LDS operations in fbank.hip: {wide}"
     assert {op for op in lds if op.endswith("_b128")} <= {"ds_write_b128"}      # the PCM tile staging only
+    # no FLAT memory operation either: a scratch pointer that loses its LDS address space (e.g. through an inline-asm operand) is read
+    # with flat_load_dwordx4 -- a 128-bit access of the scratch through the flat path, 24 % slower and outside the 32-bit forms above
+    assert not re.search(r"^\s+flat_(load|store|atomic)", body, re.M), "flat memory operations in fbank.hip"
 
 
 def test_streaming_stack_kernel_has_no_64_bit_lds_operations():

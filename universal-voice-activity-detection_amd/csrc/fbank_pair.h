@@ -263,7 +263,7 @@ __device__ __forceinline__ void fbank_pair(const float *xa, const float *xb, boo
                 const float2 w = ZB_GET((NFFT - kc) & (NFFT - 1));
                 const float ar = z.x + w.x, ai = z.y - w.y;
                 const float br = z.y + w.y, bi = z.x - w.x;
-                return make_float2(0.25f * (ar * ar + ai * ai), 0.25f * (br * br + bi * bi));
+                return make_float2(ar * ar + ai * ai, br * br + bi * bi);   // 4 x the power: the image's weights carry the 1/4 (exact)
             };
 #pragma unroll
             for (int d = 0; d < 4; ++d) pw[d] = power(lane + 64 * d);
@@ -290,12 +290,17 @@ __device__ __forceinline__ void fbank_pair(const float *xa, const float *xb, boo
                 float ea = 0.f, eb = 0.f, ea2 = 0.f, eb2 = 0.f;
                 const float *wp = melw + m;              // (columns [F, LD) of the image are zero)
                 const float *pr = zr + st;
+                // (zi == zr + ZB_ELEMS) as a base register of its own -- the OFFSET is made opaque, not the pointer (which would lose its
+                // LDS address space and turn the reads into flat loads): otherwise hipcc rebuilds the address per read pair, four adds per iteration
+                int zoff = ZB_ELEMS;
+                asm volatile("" : "+v"(zoff));
+                const float *pi = pr + zoff;
                 float w0[4], a0[4], b0[4], w1[4], a1[4], b1[4];
 #define UVAD_MEL_LOAD(W, A, B, q)                                                                                      \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
         W[j] = wp[((q) * 4 + j) * LD];                                                                                 \
         A[j] = pr[(q) * 4 + j];                                                                                        \
-        B[j] = pr[ZB_ELEMS + (q) * 4 + j];   /* zi == zr + ZB_ELEMS: one ds_read2st64_b32 with A[j] */                 \
+        B[j] = pi[(q) * 4 + j];                                                                                        \
     }
 #define UVAD_MEL_SUM(W, A, B)                                                                                          \
     ea = __builtin_fmaf(W[0], A[0], ea);   eb = __builtin_fmaf(W[0], B[0], eb);                                        \
@@ -308,7 +313,7 @@ __device__ __forceinline__ void fbank_pair(const float *xa, const float *xb, boo
                     UVAD_MEL_LOAD(w1, a1, b1, 1)
                     UVAD_MEL_SUM(w0, a0, b0)
                     UVAD_MEL_SUM(w1, a1, b1)
-                    wp += 8 * LD; pr += 8;
+                    wp += 8 * LD; pr += 8; pi += 8;
                 }
                 if (i < mel_quads) {
                     UVAD_MEL_LOAD(w0, a0, b0, 0)

@@ -353,7 +353,7 @@ int uvad_set_tables(uvad_ctx *c, const float *window, const float *mel) {
     const int ld_t = mel_image_ld(F);
     std::vector<float> wt(mel_image_floats(maxlen, F), 0.0f);
     for (int m = 0; m < F; ++m)
-        for (int i = 0; i < ln[m]; ++i) wt[(size_t)i * ld_t + m] = w[(size_t)m * maxlen + i];
+        for (int i = 0; i < ln[m]; ++i) wt[(size_t)i * ld_t + m] = 0.25f * w[(size_t)m * maxlen + i];   // the spectrum split leaves 4 |X|^2 (fbank_pair.h): exact
     if ((r = dev_upload(c, wt.data(), wt.size(), &c->d_mel_wt))) return r;
     c->tables_set = true;
     return UVAD_OK;

@@ -165,7 +165,7 @@ struct FbankTables {            // device pointers owned by the ctx
     const int *mel_start;       // [n_mels] first bin with non-zero weight
     const int *mel_len;         // [n_mels] number of bins
     const float *mel_w;         // [n_mels][mel_stride] weights (zero padded)
-    const float *mel_wt;        // the same transposed, the LDS image of the mel stage: [mel_stride][mel_image_ld(n_mels)] (zero padded)
+    const float *mel_wt;        // the same transposed, the LDS image of the mel stage: [mel_stride][mel_image_ld(n_mels)] (zero padded), x 1/4
     int mel_stride;             // the uniform trip count of the band loop: the longest band rounded up to a multiple of 4 bins
     const float *tw512;         // [512][2] (cos, -sin)(2*pi*j/512): forward FFT twiddles
     int nyquist;                // 1 if any filter weighs bin n_fft / 2 (kaldi-style tables, the reference's, carry a zero column there: the
