@@ -100,6 +100,12 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
     // All loads of the tile are issued before the first LDS write (ST_IT chunks of 4 samples per
     // thread in flight): a load -> wait -> store loop would pay the HBM latency once per chunk.
     constexpr int ST_IT = ((FR_WG - 1) * 160 + 400 + 1023) / 1024;   // one round covers the tile at the reference geometry (25 ms / 10 ms)
+    // A tile that lies wholly inside the row, on an aligned address, needs none of the per-lane range / alignment tests below: one
+    // workgroup-uniform decision (scalar arithmetic) instead of four 64-bit compares per 16-byte piece.  All but the first and last
+    // tiles of a row are of this kind.
+    const bool interior = !virt && s0 >= 0 && s0 + (int64_t)((need + 3) & ~3) <= a.S &&
+                          ((I16 ? reinterpret_cast<uintptr_t>(reinterpret_cast<const int16_t *>(xrow) + s0) & 7
+                                : reinterpret_cast<uintptr_t>(reinterpret_cast<const float *>(xrow) + s0) & 15) == 0);
     for (int base = 0; base < need; base += ST_IT * 1024) {
         float4 v[ST_IT];
 #pragma unroll
@@ -108,10 +114,10 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
             const int64_t g = s0 + i;
             v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < need) {
-                bool fast = !virt && g >= 0 && g + 3 < a.S;
+                bool fast = interior || (!virt && g >= 0 && g + 3 < a.S);
                 if (I16) {
                     const int16_t *p = reinterpret_cast<const int16_t *>(xrow) + g;
-                    fast = fast && (reinterpret_cast<uintptr_t>(p) & 7) == 0;
+                    fast = interior || (fast && (reinterpret_cast<uintptr_t>(p) & 7) == 0);
                     if (fast) {
                         const short4 q = *reinterpret_cast<const short4 *>(p);
                         v[it] = make_float4((float)q.x * (1.0f / 32768.0f), (float)q.y * (1.0f / 32768.0f),
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256, UVAD_FB_MINWAVES) void fbank_kernel(FbankArgs 
                     }
                 } else {
                     const float *p = reinterpret_cast<const float *>(xrow) + g;
-                    fast = fast && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+                    fast = interior || (fast && (reinterpret_cast<uintptr_t>(p) & 15) == 0);
                     if (fast) v[it] = *reinterpret_cast<const float4 *>(p);
                 }
                 if (!fast) {
