@@ -147,6 +147,28 @@ def test_fbank_arbitrary_mel_matrix_with_weight_on_the_last_bin(F):
     rt.set_tables(win, co.mel_banks(oc))
 
 
+def test_mel_matrix_too_wide_for_the_lds_image_is_refused_by_name():
+    """A (n_mels, 257) matrix whose longest band does not fit the feature kernel's LDS image (with 80 filters the image's rows are 128
+    floats: a dense matrix needs 260 x 128 x 4 = 133 KiB beside the PCM tile and the scratch) is refused by uvad_set_tables with a
+    message that names the band length -- not by a failing launch later."""
+    import uvad_amd
+    from oracle import c_oracle as co
+    dev = torch.device("cuda:0")
+    rt = uvad_amd.Fbank(uvad_amd.FbankConfig(num_filters=80, window_type="povey", device="cuda"))._runtime(dev)
+    dense = np.full((80, 257), 0.01, np.float32)
+    with pytest.raises(Exception, match="longest band"):
+        rt.set_tables(co.window("povey", 400), dense)
+    # a dense matrix of 40 filters (64-float rows: 65 KiB) is taken, and matches the float64 oracle
+    from oracle import torch_ref as tr
+    rt40 = uvad_amd.Fbank(uvad_amd.FbankConfig(num_filters=40, window_type="povey", device="cuda"))._runtime(dev)
+    d40 = np.random.default_rng(5).uniform(0.001, 0.02, (40, 257)).astype(np.float32)
+    rt40.set_tables(co.window("povey", 400), d40)
+    pcm = tr.synth_pcm(2, 8000, seed=3)
+    got = rt40.fbank(torch.from_numpy(pcm).to(dev)).cpu().numpy()
+    truth = co.fbank_f64(pcm, co.default_fbank_cfg(40), co.window("povey", 400), d40)
+    assert np.abs(got - truth).max() < FEAT_TOL
+
+
 def test_fbank_log_of_a_normal_floor_equals_ocml_logf_bit_for_bit():
     """fbank_pair.h log_floored(): with an energy floor that is a normal float (the reference's is FLT_EPSILON) the kernel takes
     v_log_f32 + the double-float product with ln 2 without ocml logf's subnormal-argument handling; with a floor below FLT_MIN it

@@ -338,6 +338,14 @@ int uvad_set_tables(uvad_ctx *c, const float *window, const float *mel) {
             if (ln[m] > trip) return fail(c, UVAD_E_STATE, "internal: mel band shift exceeded the trip count");
         maxlen = trip;
     }
+    {   // the feature kernel keeps the whole weight image, a PCM tile and the transform scratch in LDS: refuse here, by name, what a launch could not take
+        FbankArgs probe{};
+        probe.frame_len = c->fb.frame_len; probe.frame_shift = c->fb.frame_shift; probe.n_mels = F;
+        probe.tab.mel_stride = maxlen;
+        if (fbank_lds_bytes(probe) > 160 * 1024)
+            return fail(c, UVAD_E_UNSUPPORTED, "mel matrix: the longest band (" + std::to_string(maxlen) + " bins) makes the feature kernel's weight image (" +
+                                               std::to_string(mel_image_floats(maxlen, F) * 4) + " bytes) exceed the 160 KiB of LDS with this frame geometry");
+    }
     c->mel_stride = maxlen;
     c->mel_nyquist = 0;
     for (int m = 0; m < F; ++m)
