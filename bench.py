@@ -246,6 +246,8 @@ def main():
     proj_f, rec_f, head_f = classifier_flops_per_frame(N_MELS)
     frames_step = B * T
     rec_tile = rts[0].recurrent_tile()
+    global P2Q_ACTIVE
+    P2Q_ACTIVE = rts[0].p2_on_fp8()
     names = kernel_names(rec_tile, products=4)
     stage = {
         "fbank": {"ms": ms["fbank"], "bound": "hbm", "kernel": names["fbank"],
@@ -328,14 +330,19 @@ def main():
         raise SystemExit(f"bench.py: {n_wrong} of the last {n_fly} in-flight steps differ from a single call: the result is invalid")
 
 
-def kernel_names(rec_tile, products=4, gemm_mode="f16p"):
-    """The kernel instances a cfg-2 step launches (as rocprofv3 prints them, profiles/*_kernel_stats.csv), derived from the mode."""
+P2Q_ACTIVE = True   # set from runtime.p2_on_fp8() once the model is finalized
+
+
+def kernel_names(rec_tile, products=4, gemm_mode="f16p", p2q=None):
+    """The kernel instances a cfg-2 step launches (as rocprofv3 prints them, profiles/*_kernel_stats.csv), derived from the mode.
+    p2q: the throughput recurrence runs its fourth product on the 8-bit matrix pipe (runtime.p2_on_fp8(): third template argument)."""
+    q = "true" if ((P2Q_ACTIVE if p2q is None else p2q) and products == 4) else "false"
     if gemm_mode == "f32":
         return {"fbank": "fbank_kernel<false, true> (f32 PCM, normal energy floor)", "proj": "gemm_f32_kernel", "head": "gemm_f32_kernel + classifier_kernel",
-                "recurrent": f"lstm_rec16h_kernel<false, {products}>" if rec_tile == 16 else "lstm_rec_kernel<128, 8, false>"}
+                "recurrent": f"lstm_rec16h_kernel<false, {products}, {q}>" if rec_tile == 16 else "lstm_rec_kernel<128, 8, false>"}
     return {"fbank": "fbank_kernel<false, true> (f32 PCM, normal energy floor)", "proj": f"gemm_f16p_ws_kernel<16, {products}> (K = 256; <4, {products}> at K = 64)",
             "head": f"head_fused_kernel<8, {products}>",
-            "recurrent": f"lstm_rec16h_kernel<true, {products}>" if rec_tile == 16 else "lstm_rec_kernel<128, 8, true>"}
+            "recurrent": f"lstm_rec16h_kernel<true, {products}, {q}>" if rec_tile == 16 else "lstm_rec_kernel<128, 8, true>"}
 
 
 def start_sampler(dev):
@@ -394,7 +401,7 @@ def build_roofline(alone, B, T, rec_tile, n_cu, step_ms, n_fly, clocks):
     rec_ms = alone["recurrent_launch_ms"]
     rec_cus = min(n_cu, 2 * ((B + 15) // 16)) if f16_rec else min(n_cu, 2 * ((B + 3) // 4))
     rec_name = kernel_names(rec_tile)["recurrent"]
-    rec_q = quoted_profile(rec_name.split("<")[0] + ("<true, 4>" if f16_rec else "<128, 8, true>"), B)
+    rec_q = quoted_profile(rec_name.split("<")[0] + ("<true, 4" if f16_rec else "<128, 8, true>"), B)
     rec_ach = rec_alg / (rec_ms * 1e-3) / 1e12
     rec_peak = PEAK_F16_MFMA_TFLOPS / PRODUCTS if f16_rec else PEAK_F32_MFMA_TFLOPS
     roof = {"kernel": rec_name, "bound": "mfma", "achieved": rec_ach, "peak": rec_peak, "unit": "TFLOP/s", "frac": rec_ach / rec_peak,

@@ -270,6 +270,13 @@ int uvad_set_recurrent_tile(uvad_ctx *, int sequences);
 int uvad_set_time_chunks(uvad_ctx *, int chunks);
 int uvad_get_time_chunks(const uvad_ctx *);
 int uvad_get_recurrent_tile(const uvad_ctx *);
+/* 1 if the throughput form runs its fourth product (P2 x h, the residue plane of the exact three-way split of W_hh) on the 8-bit
+ * matrix pipe (v_mfma_scale_f32_16x16x128_f8f6f4): decided by uvad_finalize, which checks that EVERY element of every layer's P2 plane is
+ * exactly a bf8 (E5M2) number after one power-of-two shift, so the weights stay exact (the residue of two round-to-nearest f16
+ * splits of a 24-bit significand always is: at most two significant bits, within bf8's exponent range of the f16 value it replaces);
+ * 0 in GEMM mode 2 (the kernel set kept for comparisons reads P2 from its f16 image, as every mode did before round 4), if a check
+ * failed, or if the model has no hidden_size-128 layers.  h enters that one product rounded to fp8 (E4M3). */
+int uvad_get_p2_on_fp8(const uvad_ctx *);
 /* What mode 0 would launch for a batch of B sequences (4 or 16).  A sweep sharded over n GPUs that wants every utterance to
  * get the same bits as the unsharded run pins all ranks to uvad_recurrent_tile_for(ctx, GLOBAL batch) (tools/run_cfg4.py
  * --reproducible); left alone each rank picks the faster form for its own shard and results agree to rounding. */

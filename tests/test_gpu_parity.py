@@ -797,6 +797,35 @@ def test_tile16_throughput_kernel_matches_tile4():
     assert d < LOGIT_TOL
 
 
+def test_throughput_recurrence_fourth_product_on_the_fp8_pipe_equals_its_f16_form():
+    """lstm_rec16h_kernel<.., 4, true>: the P2 x h product on v_mfma_scale_f32_16x16x128_f8f6f4 (uvad_finalize verifies that every element of
+    every layer's P2 plane is exactly a bf8 number; uvad_get_p2_on_fp8).  GEMM mode 2 -- the kernel set kept for comparisons -- runs the same
+    recurrence with P2 from its f16 image (the form every mode ran before round 4): both must reproduce the reference's golden logits, and
+    they must agree with each other far inside the bound (same sums; the fp8 form rounds h to 4 bits in a term that is 2^-22 of the sum)."""
+    import uvad_amd
+    g, sd, case = load_golden("pyannet2_f64_T1000")
+    dev = torch.device("cuda:0")
+    m = _model(case, sd, dev)
+    rt = m.runtime(dev)
+    x = torch.from_numpy(g["feats"]).to(dev).repeat(10, 1, 1)[:19]         # 19 sequences: a full and a partial 16-sequence workgroup per direction
+    outs = {}
+    for mode, want_fp8 in (("f16p", True), ("f16p_stream", False)):
+        rt.set_gemm_mode(mode)
+        rt.set_recurrent_tile(16)
+        assert rt.p2_on_fp8() == want_fp8, mode
+        l, _ = m.forward_logits(x)
+        assert rt.recurrent_tile() == 16
+        err = float(np.abs(l[:2].cpu().numpy() - g["logits"]).max())
+        print(f"mode {mode}: p2_on_fp8 {rt.p2_on_fp8()}, logit err vs reference golden {err:.2e}")
+        assert err < LOGIT_TOL
+        outs[mode] = l.clone()
+    rt.set_gemm_mode("f16p")
+    rt.set_recurrent_tile(0)
+    d = float((outs["f16p"] - outs["f16p_stream"]).abs().max())
+    print(f"fp8 form vs f16 form of the P2 product: max logit diff {d:.2e}")
+    assert d < 0.05 * LOGIT_TOL
+
+
 @pytest.mark.parametrize("B,T,bidir,fc", [(40, 37, True, 2), (1, 1, True, 2), (33, 2, True, 2), (64, 129, False, 2), (17, 300, True, 0),
                                          (32, 50, True, 0), (64, 129, False, 0), (17, 3, True, 0)])
 def test_recurrent_forms_agree_on_ragged_shapes(B, T, bidir, fc):

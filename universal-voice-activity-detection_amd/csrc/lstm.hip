@@ -267,16 +267,30 @@ __global__ __launch_bounds__(WAVES * 64) void lstm_rec_kernel(LstmArgs a) {
 constexpr int R16_HP = 136;                          // f16 elements per h row in LDS (128 + pad)
 constexpr int R16_P2_ELEMS = 8 * 16 * 64 * 8;        // P2 image of one direction
 constexpr int R16_HB_ELEMS = 2 * 2 * 16 * R16_HP;    // [buffer][plane][sequence][R16_HP]
+constexpr int R16_P2Q_ELEMS = 8 * 4 * 64 * 16;       // the same image as bf8 (E5M2) bytes, counted in u16: [wave][row block][lane][32 bytes]
+constexpr int R16_HQ = 144;                          // bytes per sequence row of the fp8 image of h (128 + pad, a multiple of 16)
+constexpr int R16_HQ_ELEMS = 2 * 16 * R16_HQ / 2;    // [buffer][sequence][R16_HQ] in u16
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using i32x8 = __attribute__((ext_vector_type(8))) int;
 
 
 // NPROD = 3: without the P2 x h1 product (LstmArgs::products): no P2 image in LDS (17 KiB instead of 145), 48 MFMAs per wave and step
-template <bool PLANES, int NPROD>
+// P2Q (NPROD = 4 only): the P2 x h1 product on the 8-bit matrix pipe.  P2 is the residue of two round-to-nearest f16 splits of a 24-bit
+// significand -- 0, +-1 or +-2 units at a per-element exponent, at most two significant bits -- so, shifted by one power of two, it IS a bf8
+// (E5M2) number (pack_whh16h_p2q verifies every element; E5M2 is the upper byte of an f16) and the WEIGHTS STAY EXACT; h enters that
+// product rounded to fp8 (E4M3: a 2^-4 relative change of a term that is 2^-22 of the sum).  One v_mfma_scale_f32_16x16x128_f8f6f4 over
+// the whole K = 128 (32 cycles; operand layout and the power-of-two scale operand checked with exact integers by tools/mx_probe.hip)
+// replaces the four f16 MFMAs of a row block (64 cycles): 896 instead of 1 024 matrix cycles per wave and step, the P2 image 64 instead of
+// 128 KiB.  The k order of that product is the kernel's own: byte 16 w + 4 q + rb of a sequence's fp8 row is unit 16 w + 4 rb + q, so the
+// four cells a lane updates are one aligned dword of the image (one ds_write_b32); the host packs P2's columns in the same order.
+template <bool PLANES, int NPROD, bool P2Q>
 __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
     constexpr int H = 128, RB = 4, KST = 4;
+    static_assert(!P2Q || NPROD == 4, "the fp8 form of the P2 product exists for four products only");
     extern __shared__ __attribute__((aligned(16))) unsigned short sm16[];
-    unsigned short *p2 = sm16, *hb = sm16 + (NPROD == 4 ? R16_P2_ELEMS : 0);
+    unsigned short *p2 = sm16, *hb = sm16 + (NPROD == 4 ? (P2Q ? R16_P2Q_ELEMS : R16_P2_ELEMS) : 0);
+    unsigned char *hq = reinterpret_cast<unsigned char *>(hb + R16_HB_ELEMS);   // (P2Q) [buffer][sequence][R16_HQ] fp8 image of h
 
     const int tile16 = blockIdx.x, dir = blockIdx.y;
     const bool reverse = dir == 1;
@@ -293,11 +307,15 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
     }
     // ---- P2 image of this direction -> LDS (128 KiB, once), h buffers zeroed (h_{-1} = 0)
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.Whh16h_p2 + (size_t)dir * R16_P2_ELEMS);
         uint4 *dst = reinterpret_cast<uint4 *>(p2);
-        if constexpr (NPROD == 4)
+        if constexpr (NPROD == 4 && P2Q) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.Whh16h_p2q + (size_t)dir * R16_P2Q_ELEMS);
+            for (int i = threadIdx.x; i < R16_P2Q_ELEMS / 8; i += 512) dst[i] = src[i];
+        } else if constexpr (NPROD == 4) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.Whh16h_p2 + (size_t)dir * R16_P2_ELEMS);
             for (int i = threadIdx.x; i < R16_P2_ELEMS / 8; i += 512) dst[i] = src[i];
-        for (int i = threadIdx.x; i < R16_HB_ELEMS / 2; i += 512) reinterpret_cast<unsigned *>(hb)[i] = 0u;
+        }
+        for (int i = threadIdx.x; i < (R16_HB_ELEMS + (P2Q ? R16_HQ_ELEMS : 0)) / 2; i += 512) reinterpret_cast<unsigned *>(hb)[i] = 0u;
     }
     // this lane's sequence: tile (of 4) and row offset; lanes of missing tiles in the last workgroup are clamped
     // for loads and masked for stores
@@ -366,7 +384,10 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
     };
 
     const unsigned short *p2w = p2 + (size_t)(wave * 16) * 512 + lane * 8;   // fragment (rb, ks) at + (rb*4 + ks) * 512
+    const unsigned char *p2qw = reinterpret_cast<const unsigned char *>(p2) + ((size_t)(wave * 4) * 64 + lane) * 32;   // (P2Q) fragment rb at + rb * 2048
     const int hfrag = j * R16_HP + 8 * q;                                   // + 32 ks inside a plane
+    const int hq_rd = j * R16_HQ + 32 * q, hq_wr = j * R16_HQ + 16 * wave + 4 * q;   // (P2Q) this lane's B fragment / the dword of its four cells
+    const int p2q_scale = P2Q ? a.p2q_scale : 127;
     for (int s = 0; s < a.T; ++s) {
         const int t = reverse ? a.T - 1 - s : s;
 #pragma unroll
@@ -382,6 +403,12 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
             h1[ks] = *reinterpret_cast<const f16x8 *>(hcur + hfrag + 32 * ks);
             h2[ks] = *reinterpret_cast<const f16x8 *>(hcur + 16 * R16_HP + hfrag + 32 * ks);
         }
+        i32x8 hqf = {};
+        if constexpr (P2Q) {
+            const unsigned char *hqc = hq + (s & 1) * (16 * R16_HQ) + hq_rd;
+            const u32x4 lo4 = *reinterpret_cast<const u32x4 *>(hqc), hi4 = *reinterpret_cast<const u32x4 *>(hqc + 16);
+            hqf = i32x8{(int)lo4[0], (int)lo4[1], (int)lo4[2], (int)lo4[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+        }
         const size_t yrow = row0 + (size_t)t * SEQ_TILE;
         // Row blocks one after the other (16 MFMAs each); the P2 fragment of MFMA group f + 1 is requested from LDS before group f.
         // The kernel is bound by vector-instruction issue (~290 per wave and step: four cell updates per lane), not by the matrix
@@ -390,23 +417,34 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
         float hnew[RB];
         f32x4 gpre[RB];
         f16x8 w2n = {};
-        if constexpr (NPROD == 4) w2n = *reinterpret_cast<const f16x8 *>(p2w);
+        if constexpr (NPROD == 4 && !P2Q) w2n = *reinterpret_cast<const f16x8 *>(p2w);
+        auto p2q_frag = [&](int rb) {   // (P2Q) the bf8 fragment of row block rb: 32 bytes per lane
+            const u32x4 lo4 = *reinterpret_cast<const u32x4 *>(p2qw + rb * 2048), hi4 = *reinterpret_cast<const u32x4 *>(p2qw + rb * 2048 + 16);
+            return i32x8{(int)lo4[0], (int)lo4[1], (int)lo4[2], (int)lo4[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+        };
+        i32x8 wqn = {};
+        if constexpr (P2Q) wqn = p2q_frag(0);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             f32x4 hi = {0.f, 0.f, 0.f, 0.f}, lo = {0.f, 0.f, 0.f, 0.f};
+            const i32x8 wq = wqn;
+            if constexpr (P2Q)
+                if (rb + 1 < RB) wqn = p2q_frag(rb + 1);
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
                 const int f = rb * 4 + ks;
                 const f16x8 w2 = w2n;
-                if constexpr (NPROD == 4)
+                if constexpr (NPROD == 4 && !P2Q)
                     if (f + 1 < 16) w2n = *reinterpret_cast<const f16x8 *>(p2w + (f + 1) * 512);
                 const f16x8 w0 = __builtin_bit_cast(f16x8, w[f]);
                 const f16x8 w1 = __builtin_bit_cast(f16x8, w[16 + f]);
                 lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, h1[ks], lo, 0, 0, 0);
                 hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, h1[ks], hi, 0, 0, 0);
                 lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, h2[ks], lo, 0, 0, 0);
-                if constexpr (NPROD == 4) lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, h1[ks], lo, 0, 0, 0);
+                if constexpr (NPROD == 4 && !P2Q) lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, h1[ks], lo, 0, 0, 0);
             }
+            // (P2Q) P2 (bf8, scaled back by 2^(p2q_scale - 127)) x h (fp8) over the whole K in one instruction
+            if constexpr (P2Q) lo = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wq, hqf, lo, 1, 0, 0, p2q_scale, 0, 127);
             gpre[rb] = __builtin_elementwise_fma(__builtin_elementwise_fma(lo, f32x4{0.00048828125f, 0.00048828125f, 0.00048828125f, 0.00048828125f}, hi),
                                                  f32x4{wscale, wscale, wscale, wscale}, gq[rb]);
             gq[rb] = *reinterpret_cast<const f32x4 *>(gnext + 16 * rb);   // next step's gates of this row block: a whole step to arrive
@@ -422,6 +460,11 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
             if constexpr (!PLANES) {
                 if (live) a.Y[yrow * a.ldy + ycol + 4 * rb] = hnew[rb];   // exact-f32 output: per lane (the planes in LDS hold 22 bits)
             }
+        }
+        if constexpr (P2Q) {   // the lane's four cells (row blocks 0 .. 3 = bytes 0 .. 3) as fp8, one dword of the next step's image
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(hnew[0], hnew[1], 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(hnew[2], hnew[3], pk, true);
+            *reinterpret_cast<int *>(hq + ((s + 1) & 1) * (16 * R16_HQ) + hq_wr) = pk;
         }
         // h of the PREVIOUS step (complete in LDS since the last barrier, not overwritten before the next one) goes out now,
         // when the fragment registers of this step are dead
@@ -532,6 +575,7 @@ constexpr double REC16_ROUND_COST = 1.6;   // time of one round of the 16-sequen
 size_t whh_packed_elems(int H) { return (size_t)4 * H * H; }
 size_t whh16h_regs_elems() { return (size_t)8 * 128 * 64; }        // u32 per direction
 size_t whh16h_p2_elems() { return (size_t)R16_P2_ELEMS; }          // f16 per direction
+size_t whh16h_p2q_elems() { return (size_t)R16_P2Q_ELEMS; }        // u16 per direction (64 KiB of bf8 bytes)
 
 int lstm_waves(int H) { return H == 128 ? 8 : 4; }
 
@@ -608,6 +652,53 @@ bool pack_whh16h(const float *w_hh, unsigned *regs, unsigned short *p2, float *w
     return finite;
 }
 
+// P2 (the third plane of pack_whh16h's split) as bf8 for v_mfma_scale_f32_16x16x128_f8f6f4: [wave 8][rb 4][lane 64][32 bytes]; lane
+// (row = lane & 15, kq = lane >> 4) holds row -> (unit 16 wave + 4 rb + (row >> 2), gate row & 3), byte jj -> column k' = 32 kq + jj, where k'
+// names the SOURCE unit 16 (k' >> 4) + 4 (k' & 3) + ((k' >> 2) & 3) (the kernel's fp8 image of h keeps a lane's four cells in one dword).
+// E5M2 is the upper byte of an f16, so an element is exactly representable iff the low byte of (P2 x 2^13 as f16) is zero: P2 is 0, +-1 or
+// +-2 units of 2^(e - 12) (e = the weight's exponent after scaling, <= 13), i.e. <= 4 in magnitude and at most two significant bits.
+bool pack_whh16h_p2q(const float *w_hh, unsigned short *p2q, int *scale) {
+    const int H = 128, SHIFT = 13;
+    float amax = 0.0f;
+    for (size_t i = 0; i < (size_t)4 * H * H; ++i) {
+        const float v = __builtin_fabsf(w_hh[i]);
+        if (!(v <= 3.0e38f)) return false;
+        if (v > amax) amax = v;
+    }
+    int S = 0;
+    if (amax > 0.0f) {
+        int e;
+        (void)__builtin_frexpf(amax, &e);
+        S = 14 - e;
+        if (S > 100) S = 100;
+        if (S < -100) S = -100;
+    }
+    const float up = __builtin_ldexpf(1.0f, S);
+    *scale = 127 - SHIFT;
+    unsigned char *out = reinterpret_cast<unsigned char *>(p2q);
+    bool exact = true;
+    for (int wave = 0; wave < 8; ++wave)
+        for (int rb = 0; rb < 4; ++rb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = lane & 15, kq = lane >> 4;
+                const int unit = 16 * wave + 4 * rb + (row >> 2), gate = row & 3;
+                for (int jj = 0; jj < 32; ++jj) {
+                    const int kp = 32 * kq + jj, src = 16 * (kp >> 4) + 4 * (kp & 3) + ((kp >> 2) & 3);
+                    const float ws = w_hh[(size_t)(gate * H + unit) * H + src] * up;
+                    const _Float16 p0 = (_Float16)ws;
+                    const float t2 = (ws - (float)p0) * 2048.0f;
+                    const _Float16 p1 = (_Float16)t2;
+                    const _Float16 p2v = (_Float16)(t2 - (float)p1);
+                    const _Float16 sh = (_Float16)((float)p2v * 8192.0f);
+                    unsigned short bits;
+                    __builtin_memcpy(&bits, &sh, 2);
+                    if ((bits & 0xffu) != 0 || (float)sh != (float)p2v * 8192.0f) exact = false;
+                    out[((size_t)((wave * 4 + rb) * 64 + lane)) * 32 + jj] = (unsigned char)(bits >> 8);
+                }
+            }
+    return exact;
+}
+
 int lstm_auto_tile(int tiles, int dirs, int H, int n_cu) {
     if (H != 128) return 4;
     const int ncu = n_cu > 0 ? n_cu : 256;
@@ -644,18 +735,22 @@ hipError_t launch_lstm(const LstmArgs &a, hipStream_t s, int *tile_used) {
         const dim3 grid16((a.tiles + 3) / 4, a.dirs);
         if (a.products != 0 && a.products != 3 && a.products != 4) return hipErrorInvalidValue;
         const bool three = a.products == 3;
-        const size_t lds = (size_t)((three ? 0 : R16_P2_ELEMS) + R16_HB_ELEMS) * sizeof(unsigned short);   // 145 KiB (17 without the P2 image): one workgroup per CU (registers)
-        const void *fn = planes ? (three ? reinterpret_cast<const void *>(lstm_rec16h_kernel<true, 3>) : reinterpret_cast<const void *>(lstm_rec16h_kernel<true, 4>))
-                                : (three ? reinterpret_cast<const void *>(lstm_rec16h_kernel<false, 3>) : reinterpret_cast<const void *>(lstm_rec16h_kernel<false, 4>));
+        const bool q8 = !three && a.Whh16h_p2q != nullptr;   // the P2 product on the 8-bit matrix pipe (weights verified exact as bf8)
+        // 145 KiB with the f16 P2 image, 86 with the bf8 one, 17 without: one workgroup per CU either way (registers)
+        const size_t lds = (size_t)((three ? 0 : q8 ? R16_P2Q_ELEMS : R16_P2_ELEMS) + R16_HB_ELEMS + (q8 ? R16_HQ_ELEMS : 0)) * sizeof(unsigned short);
+        const void *fn = planes ? (three ? reinterpret_cast<const void *>(lstm_rec16h_kernel<true, 3, false>)
+                                         : q8 ? reinterpret_cast<const void *>(lstm_rec16h_kernel<true, 4, true>) : reinterpret_cast<const void *>(lstm_rec16h_kernel<true, 4, false>))
+                                : (three ? reinterpret_cast<const void *>(lstm_rec16h_kernel<false, 3, false>)
+                                         : q8 ? reinterpret_cast<const void *>(lstm_rec16h_kernel<false, 4, true>) : reinterpret_cast<const void *>(lstm_rec16h_kernel<false, 4, false>));
         {   // the attribute belongs to the (function, device) pair and a process may own contexts on several GPUs (include/uvad.h), so it
             // is set for the CURRENT device on every launch (as launch_fbank / launch_sinc_conv do; no process-global "done" flag)
             const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        if (planes && three) hipLaunchKernelGGL((lstm_rec16h_kernel<true, 3>), grid16, dim3(512), lds, s, a);
-        else if (planes) hipLaunchKernelGGL((lstm_rec16h_kernel<true, 4>), grid16, dim3(512), lds, s, a);
-        else if (three) hipLaunchKernelGGL((lstm_rec16h_kernel<false, 3>), grid16, dim3(512), lds, s, a);
-        else hipLaunchKernelGGL((lstm_rec16h_kernel<false, 4>), grid16, dim3(512), lds, s, a);
+        LstmArgs args = a;
+        void *params[] = {&args};
+        const hipError_t e = hipLaunchKernel(fn, grid16, dim3(512), params, lds, s);
+        if (e != hipSuccess) return e;
         return hipGetLastError();
     }
     if (tile_used) *tile_used = 4;

@@ -33,6 +33,8 @@ struct LayerDev {
     float *w_ih_img = nullptr;   // causal H = 128 models: W_ih as a register image (lstm_stack.hip), else nullptr
     unsigned *w_hh16_regs = nullptr;        // 16-sequence kernel (H = 128): [dirs][P0 / P1 register image]
     unsigned short *w_hh16_p2 = nullptr;    // [dirs][P2 LDS image]
+    unsigned short *w_hh16_p2q = nullptr;   // [dirs][the same as bf8 bytes] (nullptr: not every element is exactly representable)
+    int w_hh16_p2q_scale = 127;
     float *w_hh16_scale = nullptr;          // [dirs] 2^-S
     bool w_hh16_ok = false;
     int in = 0;
@@ -424,6 +426,9 @@ int uvad_finalize(uvad_ctx *c) {
         std::vector<float> wp((size_t)D * 4 * H * inp, 0.0f), bp((size_t)D * 4 * H), hh((size_t)D * whh_packed_elems(H));
         std::vector<unsigned> hh16r(H == 128 ? (size_t)D * whh16h_regs_elems() : 0, 0u);
         std::vector<unsigned short> hh16p(H == 128 ? (size_t)D * whh16h_p2_elems() : 0, 0);
+        std::vector<unsigned short> hh16q(H == 128 ? (size_t)D * whh16h_p2q_elems() : 0, 0);
+        bool hh16q_ok = H == 128;
+        int hh16q_scale = 127;
         std::vector<float> hh16s(D, 1.0f);
         bool hh16ok = H == 128;
         std::vector<float> ih_img;
@@ -449,6 +454,7 @@ int uvad_finalize(uvad_ctx *c) {
             }
             if (H == 128 && !pack_whh16h(whh->data.data(), &hh16r[(size_t)d * whh16h_regs_elems()], &hh16p[(size_t)d * whh16h_p2_elems()], &hh16s[d]))
                 hh16ok = false;
+            if (H == 128 && !pack_whh16h_p2q(whh->data.data(), &hh16q[(size_t)d * whh16h_p2q_elems()], &hh16q_scale)) hh16q_ok = false;
         }
         LayerDev &L = c->layers[k];
         L.in = in;
@@ -465,6 +471,9 @@ int uvad_finalize(uvad_ctx *c) {
         if (H == 128) {
             if ((r = dev_upload(c, hh16r.data(), hh16r.size(), &L.w_hh16_regs, true))) return r;
             if ((r = dev_upload(c, hh16p.data(), hh16p.size(), &L.w_hh16_p2, true))) return r;
+            L.w_hh16_p2q = nullptr;
+            L.w_hh16_p2q_scale = hh16q_scale;
+            if (hh16q_ok && (r = dev_upload(c, hh16q.data(), hh16q.size(), &L.w_hh16_p2q, true))) return r;
             if ((r = dev_upload(c, hh16s.data(), hh16s.size(), &L.w_hh16_scale, true))) return r;
         }
         L.w_hh16_ok = hh16ok;
@@ -1016,7 +1025,11 @@ static int classify_impl(uvad_ctx *c, const float *d_feats, int B, int T, float 
         if (c->timing) HIPCHK(c, hipEventRecord(c->layer_ev[2 * k + 1], s));
         LstmArgs r{};
         r.G = G; r.ldg = N4; r.Whh_packed = L.w_hh; r.ldy = w.Wd;
-        if (L.w_hh16_ok) { r.Whh16h_regs = L.w_hh16_regs; r.Whh16h_p2 = L.w_hh16_p2; r.whh16h_scale = L.w_hh16_scale; }
+        if (L.w_hh16_ok) {
+            r.Whh16h_regs = L.w_hh16_regs; r.Whh16h_p2 = L.w_hh16_p2; r.whh16h_scale = L.w_hh16_scale;
+            r.Whh16h_p2q = c->gemm_mode == 2 ? nullptr : L.w_hh16_p2q;   // mode 2 = the kernel set kept for comparisons: P2 from its f16 image
+            r.p2q_scale = L.w_hh16_p2q_scale;
+        }
         if (y_planes(k)) { r.Yh = hi_of(w.off_Y[k & 1]); r.Yl = lo_of(w.off_Y[k & 1], w.Wd); }
         else r.Y = Yf(k & 1);
         r.tiles = w.tiles; r.T = T; r.H = H; r.dirs = D; r.tile_mode = ss ? 4 : c->rec_tile_mode; r.n_cu = c->n_cu;
@@ -1332,6 +1345,13 @@ int uvad_set_recurrent_tile(uvad_ctx *c, int sequences) {
 }
 
 int uvad_get_recurrent_tile(const uvad_ctx *c) { return c ? c->rec_tile_used : UVAD_E_ARG; }
+int uvad_get_p2_on_fp8(const uvad_ctx *c) {
+    if (!c) return UVAD_E_ARG;
+    if (!c->has_model || !c->finalized || c->mc.hidden != 128 || c->gemm_mode == 2) return 0;
+    for (const LayerDev &L : c->layers)
+        if (!L.w_hh16_ok || !L.w_hh16_p2q) return 0;
+    return 1;
+}
 
 int uvad_set_time_chunks(uvad_ctx *c, int chunks) {
     if (!c) return UVAD_E_ARG;

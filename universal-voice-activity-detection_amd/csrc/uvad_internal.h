@@ -97,6 +97,9 @@ struct LstmArgs {
     const float *Whh_packed;     // per dir: register image, see pack_whh()
     // 16-sequence form (H = 128 only, pack_whh16h): per dir the P0 / P1 register image, the P2 LDS image, and 2^-S
     const unsigned *Whh16h_regs; const unsigned short *Whh16h_p2; const float *whh16h_scale;
+    // ... and (optional) the P2 image as bf8 bytes for the 8-bit matrix pipe (pack_whh16h_p2q; nullptr: the f16 image is used) with the
+    // E8M0 scale operand that undoes its power-of-two shift
+    const unsigned short *Whh16h_p2q; int p2q_scale;
     float *Y; int ldy;           // f32 output (exact-f32 GEMM mode), or
     unsigned short *Yh, *Yl;     // the two K-blocked f16 planes (ldy columns) h ~= hi + lo * 2^-11 the f16p GEMM of the next layer reads (Y == nullptr)
     int products;                // 16-sequence form: 4 (0 reads as 4) or 3 (no P2 plane: see GemmArgs)
@@ -120,6 +123,10 @@ void pack_whh(const float *w_hh, int H, float *out);
 size_t whh16h_regs_elems();
 size_t whh16h_p2_elems();
 bool pack_whh16h(const float *w_hh, unsigned *regs, unsigned short *p2, float *wscale);   // false: a weight is non-finite
+size_t whh16h_p2q_elems();
+// the P2 image as bf8 (E5M2) bytes, columns in the kernel's k order; false if some element is not exactly representable (the f16 image
+// then stays in use); *scale = the E8M0 scale operand (127 - shift)
+bool pack_whh16h_p2q(const float *w_hh, unsigned short *p2q, int *scale);
 
 // ---- head.hip -----------------------------------------------------------------------------
 // logit = Z[m][:K] . w + b ; prob = sigmoid(logit); written at canonical [b][t] (b < B only).

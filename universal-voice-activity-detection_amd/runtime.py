@@ -325,6 +325,10 @@ class VadRuntime:
         """What the most recent classify / forward launched (4 or 16)."""
         return int(self.lib.uvad_get_recurrent_tile(self.ctx))
 
+    def p2_on_fp8(self) -> bool:
+        """True if the 16-sequence recurrence runs its P2 x h product on the 8-bit matrix pipe (every P2 element exactly bf8: include/uvad.h)."""
+        return bool(self.lib.uvad_get_p2_on_fp8(self.ctx))
+
     def set_time_chunks(self, chunks: int):
         """Time chunks per layer for a batch that runs alone (include/uvad.h): 0 = automatic (default), 1 = off, n = that many.  The
         projection of chunk i + 1 runs on a stream of the library's own beside the recurrence of chunk i; outputs are bit-identical."""
