@@ -264,8 +264,10 @@ def main():
         if k == "recurrent" and rec_tile != 16:
             stage[k].update({"frac": alg / PEAK_F32_MFMA_TFLOPS, "peak": "f32 MFMA 157.3 TFLOP/s (v_mfma_f32_4x4x1_16B_f32: one product per product)"})
         else:
-            stage[k].update({"issued_f16_TFLOPs": PRODUCTS * alg, "frac": PRODUCTS * alg / PEAK_F16_MFMA_TFLOPS,
-                             "peak": "issued: f16 MFMA 2500 TFLOP/s; algorithmic: 2500 / 4 products = 625 TFLOP/s f32-equivalent (same fraction)",
+            units = 3.5 if (k == "recurrent" and P2Q_ACTIVE) else PRODUCTS   # f16-product times per f32-equivalent product (an fp8 MX product: a half)
+            stage[k].update({"issued_f16_TFLOPs": units * alg, "frac": units * alg / PEAK_F16_MFMA_TFLOPS,
+                             "peak": "issued, in f16-product times: f16 MFMA 2500 TFLOP/s (the recurrence's fourth product runs on the 8-bit pipe at twice "
+                                     "that rate and counts a half); algorithmic: 2500 / 4 (3.5) = 625 (714) TFLOP/s f32-equivalent (same fraction)",
                              "frac_vs_f32_mfma_peak": alg / PEAK_F32_MFMA_TFLOPS})
     for k in stage:
         stage[k]["note"] = "HIP-event time inside the timed region: stretched by the other in-flight steps' kernels; not a kernel figure"
@@ -282,8 +284,9 @@ def main():
         "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f16x4: f32-equivalent arithmetic on the f16 matrix cores -- exact f32 weights as 3 f16 planes x activations as 2 f16 planes "
-                 "(22 bits), 4 v_mfma_f32_*_f16 products per f32 product, f32 accumulate; recurrence state, gate functions, features and "
-                 "outputs f32.  `all_f32` = the same step on v_mfma_f32_* only (GEMMs and recurrence); `f32_gemm` = f32-MFMA GEMMs with "
+                 "(22 bits), 4 matrix products per f32 product (v_mfma_f32_*_f16; in the recurrence the fourth -- the weights' residue plane, "
+                 "exactly representable as bf8, times h rounded to fp8 -- on v_mfma_scale_f32_16x16x128_f8f6f4), f32 accumulate; recurrence state, "
+                 "gate functions, features and outputs f32.  `all_f32` = the same step on v_mfma_f32_* only (GEMMs and recurrence); `f32_gemm` = f32-MFMA GEMMs with "
                  "the split-f16 recurrence",
         "data": "synthetic",
         "config": {"workload": f"batch={B} x 10 s synthetic 16 kHz per GPU, 25 ms/10 ms frames, 64-bin log-mel (hamming) + "
@@ -403,7 +406,10 @@ def build_roofline(alone, B, T, rec_tile, n_cu, step_ms, n_fly, clocks):
     rec_name = kernel_names(rec_tile)["recurrent"]
     rec_q = quoted_profile(rec_name.split("<")[0] + ("<true, 4" if f16_rec else "<128, 8, true>"), B)
     rec_ach = rec_alg / (rec_ms * 1e-3) / 1e12
-    rec_peak = PEAK_F16_MFMA_TFLOPS / PRODUCTS if f16_rec else PEAK_F32_MFMA_TFLOPS
+    # matrix-pipe time of one f32-equivalent product of the recurrence, in units of ONE f16 product: four f16 products, or -- with the
+    # fourth on v_mfma_scale_*_f8f6f4, which runs at twice the f16 rate -- three and a half
+    rec_units = (3.5 if P2Q_ACTIVE else PRODUCTS) if f16_rec else 1.0
+    rec_peak = PEAK_F16_MFMA_TFLOPS / rec_units if f16_rec else PEAK_F32_MFMA_TFLOPS
     roof = {"kernel": rec_name, "bound": "mfma", "achieved": rec_ach, "peak": rec_peak, "unit": "TFLOP/s", "frac": rec_ach / rec_peak,
             "traffic": rec_q["traffic"], "traffic_unit": "bytes/launch", "traffic_source": rec_q["traffic_source"],
             "algorithmic_bytes_per_launch": Mrows * (1024 * 4 + 256 * 4),
@@ -414,12 +420,20 @@ def build_roofline(alone, B, T, rec_tile, n_cu, step_ms, n_fly, clocks):
             "vs_f32_mfma_peak": {"peak": PEAK_F32_MFMA_TFLOPS, "frac": rec_ach / PEAK_F32_MFMA_TFLOPS,
                                  "what": "the algorithmic rate against SURVEY 8(d)'s f32-MFMA ceiling (a different pipe: no f32 MFMA is issued in this kernel)"},
             "how": "achieved = algorithmic_flops_per_launch / launch_ms_alone_on_gpu (HIP events around the launch, the step submitted ALONE; the "
-                   "rocprofv3 average of the same launches: rocprofv3.avg_launch_ms); peak = 2500 TFLOP/s dense f16 MFMA / 4 products per "
-                   "f32-equivalent product; issued.* = the same launch counted in issued f16 products against the 2500 (same fraction)"}
+                   "rocprofv3 average of the same launches: rocprofv3.avg_launch_ms); peak = the f32-equivalent ceiling of the kernel's own "
+                   "instruction mix: 2500 TFLOP/s dense f16 MFMA / (3 f16 products + 1 fp8 product at twice the f16 rate = 3.5 f16-product "
+                   "times) = 714 TFLOP/s with the fourth product on the 8-bit pipe, 2500 / 4 = 625 without; issued.* = the same launch "
+                   "counted in issued products against the pipes' peaks (the same fraction: the matrix pipe's occupancy)"}
     if f16_rec:
-        roof["issued"] = {"f16_mfma_flops_per_launch": PRODUCTS * rec_alg, "achieved": PRODUCTS * rec_ach, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                          "frac": PRODUCTS * rec_ach / PEAK_F16_MFMA_TFLOPS,
-                          "frac_on_occupied_cus": PRODUCTS * rec_ach / (PEAK_F16_MFMA_TFLOPS * rec_cus / n_cu)}
+        n16 = 3.0 if P2Q_ACTIVE else PRODUCTS
+        roof["issued"] = {"f16_mfma_flops_per_launch": n16 * rec_alg, "fp8_mfma_flops_per_launch": (PRODUCTS - n16) * rec_alg,
+                          "achieved": PRODUCTS * rec_ach, "unit": "TFLOP/s",
+                          "peak": PEAK_F16_MFMA_TFLOPS * PRODUCTS / rec_units,
+                          "peak_what": "issued FLOP over the matrix-pipe time they need: f16 products at 2500 TFLOP/s, fp8 (MX) products at 5000",
+                          "frac": rec_units * rec_ach / PEAK_F16_MFMA_TFLOPS,
+                          "frac_on_occupied_cus": rec_units * rec_ach / (PEAK_F16_MFMA_TFLOPS * rec_cus / n_cu)}
+        roof["vs_four_f16_products_ceiling"] = {"peak": PEAK_F16_MFMA_TFLOPS / PRODUCTS, "frac": rec_ach / (PEAK_F16_MFMA_TFLOPS / PRODUCTS),
+                                                "what": "the same algorithmic rate against the ceiling the rounds before quoted (all four products on the f16 pipe)"}
     # -- the K = 256 projection
     gemm_alg = 2.0 * Mrows * 1024 * K_hid
     gms = alone["proj_k256_ms"]
@@ -440,11 +454,13 @@ def build_roofline(alone, B, T, rec_tile, n_cu, step_ms, n_fly, clocks):
                                           "cu_ms": {"recurrence": 4 * rec_ms * rec_cus, "projections": (3 * gms + alone["proj_layer0_ms"]) * n_cu}}
     # -- the whole step at the headline rate
     f32eq = frames * (proj_f + rec_f + head_f)
-    issued = PRODUCTS * f32eq if f16_rec else PRODUCTS * frames * (proj_f + head_f) + frames * rec_f
+    # in f16-product times (the recurrence's fp8 product counts a half)
+    issued = PRODUCTS * frames * (proj_f + head_f) + rec_units * frames * rec_f
     ws = {"ms_per_step": step_ms, "steps_in_flight": n_fly,
           "issued_f16": {"achieved": issued / (step_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": issued / (step_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
-                         "what": "every MFMA product issued in a step over the headline step time"},
+                         "what": "every MFMA product issued in a step, in f16-product times (an fp8 MX product of the recurrence counts a half: it runs at "
+                                 "twice the rate), over the headline step time: the matrix pipes' occupancy"},
           "algorithmic": {"achieved": f32eq / (step_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / PRODUCTS, "unit": "TFLOP/s",
                           "frac": f32eq / (step_ms * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS / PRODUCTS),
                           "frac_vs_f32_mfma_peak": f32eq / (step_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
