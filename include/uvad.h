@@ -247,8 +247,9 @@ int uvad_set_gemm_mode(uvad_ctx *, int mode);
 
 /* How many sequences one recurrent workgroup owns (the time loop of nn.LSTM, PyanNet2.py:169-172):
  *   4   latency form (v_mfma_f32_4x4x1): B/4 x directions workgroups, the right one up to a few hundred sequences;
- *   16  throughput form (hidden_size 128 only): W_hh * h as four v_mfma_f32_16x16x32_f16 products on the same exact
- *       three-plane split as GEMM mode 1; a quarter of the workgroups, each 1.4 x as long: a third of the CU-time per
+ *   16  throughput form (hidden_size 128 only): W_hh * h as four matrix-core products on the same exact three-plane
+ *       split as GEMM mode 1 (three v_mfma_f32_16x16x32_f16; the fourth -- the residue plane, exactly bf8 -- on
+ *       v_mfma_scale_f32_16x16x128_f8f6f4: uvad_get_p2_on_fp8); a quarter of the workgroups, each 1.35 x as long: a third of the CU-time per
  *       sequence.  The right one for B >= 1024 and for callers that keep several batches in flight on separate contexts;
  *   0   (default) chosen per call: the form with fewer estimated rounds of workgroups over the CUs (uvad_recurrent_tile_for).
  * uvad_get_recurrent_tile returns what the most recent uvad_classify / uvad_forward* call launched (4 or 16; 0 before
