@@ -250,3 +250,35 @@ def test_sincnet_frame_time_geometry_matches_the_reference_fixture():
         assert pp.merge_intervals_with_buffer(m["intervals"], m["duration"], m["buffer"]) == m["merged"]
     for m in g["split"]:
         assert pp.split_into_windows(m["intervals"], m["window"]) == m["split"]
+
+
+def test_residue_plane_of_the_three_way_f16_split_is_always_exactly_bf8():
+    """The claim behind lstm_rec16h_kernel's fp8 product (csrc/lstm.hip pack_whh16h_p2q): with w scaled so that the
+    largest magnitude lies in [2^13, 2^14), p0 = f16(ws), t2 = (ws - p0) * 2^11, p1 = f16(t2), the residue p2 = f16(t2 - p1) -- the
+    third plane, which makes p0 + (p1 + p2) / 2^11 reproduce ws -- times 2^13 is ALWAYS exactly a bf8 (E5M2) number: E5M2 is the upper
+    byte of an f16, so the low byte of f16(p2 * 2^13) must be zero and the product must not round.  Restated in numpy (float16 casts
+    round to nearest even, as _Float16 casts do) over 4 million weights: uniform, normal, log-uniform over 30 binades, denormal-prone
+    tiny ones and exact powers of two."""
+    rng = np.random.default_rng(20)
+    parts = [rng.uniform(-1, 1, 1 << 20), rng.normal(0, 0.2, 1 << 20),
+             np.exp2(rng.uniform(-30, 0, 1 << 20)) * rng.choice([-1.0, 1.0], 1 << 20),
+             np.exp2(rng.integers(-40, 1, 1 << 19).astype(np.float64)), rng.uniform(-1e-6, 1e-6, 1 << 19)]
+    w = np.concatenate(parts).astype(np.float32)
+    w[0] = 0.999   # the largest magnitude decides the scale
+    e = int(np.frexp(np.abs(w).max())[1])
+    ws = (w * np.float32(2.0 ** (14 - e))).astype(np.float32)
+    assert 2.0 ** 13 <= np.abs(ws).max() < 2.0 ** 14
+    p0 = ws.astype(np.float16)
+    t2 = ((ws - p0.astype(np.float32)) * np.float32(2048.0)).astype(np.float32)
+    p1 = t2.astype(np.float16)
+    p2 = (t2 - p1.astype(np.float32)).astype(np.float16)
+    assert np.abs(p2.astype(np.float32)).max() <= 4.0
+    sh32 = p2.astype(np.float32) * np.float32(8192.0)
+    sh = sh32.astype(np.float16)
+    assert np.array_equal(sh.astype(np.float32), sh32)                       # the shift itself never rounds or overflows
+    bits = sh.view(np.uint16)
+    assert not (bits & 0xFF).any(), "a residue with more than two significant bits: not a bf8 number"
+    # and the three planes do reproduce the scaled weight wherever f16 can hold the residue at all (|ws| >= 2^-1: p2's unit >= 2^-24 x 2^11)
+    big = np.abs(ws) >= 0.5
+    rec = p0.astype(np.float64) + (p1.astype(np.float64) + p2.astype(np.float64)) / 2048.0
+    assert np.array_equal(rec[big], ws.astype(np.float64)[big])
