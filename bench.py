@@ -234,6 +234,10 @@ def main():
     n_wrong = sum(int(not torch.equal(p.result()[0], alone)) for p in recent)
     lat = sorted(p.elapsed_ms() for p in all_steps)
     del recent, alone, all_steps
+    # what every rank actually did (the first real N > 1 run proves RCCL saw N ranks, and a rank whose stream probe settled for fewer
+    # steps in flight -- RCCL's own streams share the 16 hardware queues -- shows here instead of silently halving the rate)
+    per_rank = udist.all_gather_floats([float(rank), float(n_fly), B * T * args.steps / elapsed, elapsed, float(dev.index or 0)],
+                                       device=dev if world > 1 else None)
     elapsed = udist.max_over_ranks(elapsed, device=dev if world > 1 else None)
     log(f"{args.steps} steps in {elapsed:.3f} s")
     if not live_events:
@@ -268,7 +272,7 @@ def main():
             stage[k].update({"issued_f16_TFLOPs": units * alg, "frac": units * alg / PEAK_F16_MFMA_TFLOPS,
                              "peak": "issued, in f16-product times: f16 MFMA 2500 TFLOP/s (the recurrence's fourth product runs on the 8-bit pipe at twice "
                                      "that rate and counts a half); algorithmic: 2500 / 4 (3.5) = 625 (714) TFLOP/s f32-equivalent (same fraction)",
-                             "frac_vs_f32_mfma_peak": alg / PEAK_F32_MFMA_TFLOPS})
+                             "ratio_to_f32_mfma_peak": alg / PEAK_F32_MFMA_TFLOPS})
     for k in stage:
         stage[k]["note"] = "HIP-event time inside the timed region: stretched by the other in-flight steps' kernels; not a kernel figure"
 
@@ -299,6 +303,10 @@ def main():
         "classifier_f32_equivalent_TFLOPs": frames_step * (proj_f + rec_f + head_f) / (step_ms * 1e-3) / 1e12,
     }
     out["in_flight_outputs_identical_to_single_call"] = n_wrong == 0
+    out["ranks"] = {"ranks_seen": len(per_rank), "backend": udist.backend_name(),
+                    "per_rank": [{"rank": int(r[0]), "steps_in_flight": int(r[1]), "value": r[2], "seconds": r[3], "cuda_device": int(r[4])} for r in per_rank],
+                    "what": "all-gather over the process group after the timed region: each rank's own frames/s over its own elapsed time "
+                            "(`value` above = all ranks' frames over the MAX elapsed time) and the steps in flight its stream probe settled for"}
     out["config"]["steps_in_flight"] = n_fly
     out["config"]["recurrent_tile"] = rts[0].recurrent_tile()
     if clocks is not None:
@@ -327,6 +335,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out.update(cpu_baseline_and_error(model, rt, pcm, dev))
     if rank == 0:
+        bad = fracs_above_one(out)
+        if bad:      # a roofline fraction above 1 is a bookkeeping error, never a measurement: refuse to print the line
+            raise SystemExit(f"bench.py: roofline fraction(s) above 1: {bad}")
         print(json.dumps(out), flush=True)
     udist.barrier()
     if n_wrong:
@@ -334,6 +345,23 @@ def main():
 
 
 P2Q_ACTIVE = True   # set from runtime.p2_on_fp8() once the model is finalized
+
+
+def fracs_above_one(obj, path=""):
+    """Every key that starts with "frac" (a fraction of a peak of the pipe the kernel runs on) whose value exceeds 1, anywhere on the line.
+    Quotients against a DIFFERENT pipe's peak (SURVEY 8(d)'s f32-MFMA ceiling for kernels that issue f16 products) are named `ratio`."""
+    bad = []
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            here = f"{path}.{k}" if path else str(k)
+            if isinstance(v, (dict, list)):
+                bad += fracs_above_one(v, here)
+            elif str(k).startswith("frac") and isinstance(v, (int, float)) and v > 1.0:
+                bad.append((here, v))
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            bad += fracs_above_one(v, f"{path}[{i}]")
+    return bad
 
 
 def kernel_names(rec_tile, products=4, gemm_mode="f16p", p2q=None):
@@ -417,7 +445,7 @@ def build_roofline(alone, B, T, rec_tile, n_cu, step_ms, n_fly, clocks):
             "why_this_kernel": "largest share of the step's kernel time with the step submitted alone (rocprofv3 --kernel-trace --stats; `rocprofv3` below)",
             "rocprofv3": rec_q["rocprofv3"], "cus_occupied": rec_cus,
             "frac_on_occupied_cus": rec_ach / (rec_peak * rec_cus / n_cu),
-            "vs_f32_mfma_peak": {"peak": PEAK_F32_MFMA_TFLOPS, "frac": rec_ach / PEAK_F32_MFMA_TFLOPS,
+            "vs_f32_mfma_peak": {"peak": PEAK_F32_MFMA_TFLOPS, "ratio": rec_ach / PEAK_F32_MFMA_TFLOPS,
                                  "what": "the algorithmic rate against SURVEY 8(d)'s f32-MFMA ceiling (a different pipe: no f32 MFMA is issued in this kernel)"},
             "how": "achieved = algorithmic_flops_per_launch / launch_ms_alone_on_gpu (HIP events around the launch, the step submitted ALONE; the "
                    "rocprofv3 average of the same launches: rocprofv3.avg_launch_ms); peak = the f32-equivalent ceiling of the kernel's own "
@@ -443,7 +471,7 @@ def build_roofline(alone, B, T, rec_tile, n_cu, step_ms, n_fly, clocks):
                           "achieved": g_ach, "peak": PEAK_F16_MFMA_TFLOPS / PRODUCTS, "unit": "TFLOP/s", "frac": g_ach / (PEAK_F16_MFMA_TFLOPS / PRODUCTS),
                           "issued": {"f16_mfma_flops_per_launch": PRODUCTS * gemm_alg, "achieved": PRODUCTS * g_ach, "peak": PEAK_F16_MFMA_TFLOPS,
                                      "frac": PRODUCTS * g_ach / PEAK_F16_MFMA_TFLOPS},
-                          "vs_f32_mfma_peak": {"peak": PEAK_F32_MFMA_TFLOPS, "frac": g_ach / PEAK_F32_MFMA_TFLOPS},
+                          "vs_f32_mfma_peak": {"peak": PEAK_F32_MFMA_TFLOPS, "ratio": g_ach / PEAK_F32_MFMA_TFLOPS},
                           "algorithmic_flops_per_launch": gemm_alg, "launch_ms_alone_on_gpu": gms, "launches_per_step": 3,
                           "traffic": g_q["traffic"], "traffic_source": g_q["traffic_source"], "rocprofv3": g_q["rocprofv3"],
                           "algorithmic_bytes_per_launch": Mrows * (K_hid * 2 * 2 + 1024 * 4),
@@ -463,7 +491,7 @@ def build_roofline(alone, B, T, rec_tile, n_cu, step_ms, n_fly, clocks):
                                  "twice the rate), over the headline step time: the matrix pipes' occupancy"},
           "algorithmic": {"achieved": f32eq / (step_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / PRODUCTS, "unit": "TFLOP/s",
                           "frac": f32eq / (step_ms * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS / PRODUCTS),
-                          "frac_vs_f32_mfma_peak": f32eq / (step_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                          "ratio_to_f32_mfma_peak": f32eq / (step_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                           "what": "SURVEY 8(d) classifier FLOP per frame x frames over the step time vs the f32-accurate ceiling of the f16 pipe "
                                   "(2500 / 4 products) and vs the f32-MFMA peak of 8(d) (157.3 TFLOP/s)"}}
     if clocks is not None and clocks.get("sclk_mhz"):
@@ -630,7 +658,12 @@ def sequential_latency(rt, dev, pcm, steps, world, forced=0):
     udist.barrier()
     dt = udist.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 else None)
     frames = world * pcm.shape[0] * rt.num_frames(pcm.shape[1]) * steps
-    # the recurrent kernel's launch duration when it has the GPU to itself (3 more steps with stage events)
+    chunks_used = rt.time_chunks()
+    # Launch durations with the GPU to itself (3 more steps with stage events), taken with ONE launch per layer and stage
+    # (set_time_chunks(1)): with time-chunked layers the stage events bracket only what the caller's stream waits for -- the exposed
+    # chunk-0 projection and six chunk recurrences with their event waits -- not one launch (that gave frac 1.67).
+    rt.set_time_chunks(1)
+    rt.forward(pcm, want_probs=False)
     rt.set_timing(True)
     rec = proj = 0.0
     for _ in range(3):
@@ -640,6 +673,7 @@ def sequential_latency(rt, dev, pcm, steps, world, forced=0):
         proj += tm["proj"]
     rt.set_timing(False)
     used = rt.recurrent_tile()
+    rt.set_time_chunks(0)                 # back to the automatic choice
     rt.set_recurrent_tile(forced)
     proj_f, rec_f, _ = classifier_flops_per_frame(N_MELS)
     launch_ms = rec / 3 / 4
@@ -647,6 +681,8 @@ def sequential_latency(rt, dev, pcm, steps, world, forced=0):
     proj_ms = proj / 3 / 4
     ptf = pcm.shape[0] * rt.num_frames(pcm.shape[1]) * proj_f / 4 / (proj_ms * 1e-3) / 1e12
     return {"value": frames / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps_in_flight": 1, "recurrent_tile": used,
+            "time_chunks_in_the_timed_steps": chunks_used,
+            "launch_timing": "avg_launch_ms below: one launch per layer (time chunks off for that pass), HIP events on the caller's stream",
             "roofline": {"kernel": kernel_names(used)["recurrent"], "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": launch_ms,
                          "what": "exact-f32 MFMA (v_mfma_f32_4x4x1_16B_f32): issued = algorithmic FLOP, f32-MFMA peak"},

@@ -125,10 +125,11 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
     }
     __syncthreads();
     int c_cur = __builtin_amdgcn_readfirstlane(qword[0]), c_nxt = __builtin_amdgcn_readfirstlane(qword[1]);
-    if (c_cur >= my_tiles) return;   // nothing left for this workgroup (no DMA issued yet)
+    // (queue indices are compared UNSIGNED everywhere: a word that is not a tile index -- negative included -- can never reach rowtile())
+    if ((unsigned)c_cur >= (unsigned)my_tiles) return;   // nothing left for this workgroup (no DMA issued yet)
     // the row tiles behind the two queue indices (a queue index past the end reads as the current tile: its DMAs re-read that tile)
     int r_cur = __builtin_amdgcn_readfirstlane(rowtile(c_cur));
-    int r_nxt = c_nxt < my_tiles ? __builtin_amdgcn_readfirstlane(rowtile(c_nxt)) : r_cur;
+    int r_nxt = (unsigned)c_nxt < (unsigned)my_tiles ? __builtin_amdgcn_readfirstlane(rowtile(c_nxt)) : r_cur;
 
     // ---- the wave's W fragments for the whole K: lane (fr, fh) holds W[n_tile * 128 + wave * 32 + fr][16 kb + 8 fh .. + 8] of each plane
     static_assert(NPROD == 3 || NPROD == 4, "three or four products");
@@ -343,12 +344,12 @@ __global__ __launch_bounds__(256, 1) void gemm_f16p_ws_kernel(GemmArgs a, int mt
         c_cur = c_nxt;
         r_cur = r_nxt;
         c_nxt = __builtin_amdgcn_readfirstlane(c_nn);
-        r_nxt = c_nxt < my_tiles ? __builtin_amdgcn_readfirstlane(rowtile(c_nxt)) : r_cur;
+        r_nxt = (unsigned)c_nxt < (unsigned)my_tiles ? __builtin_amdgcn_readfirstlane(rowtile(c_nxt)) : r_cur;
     };
     tile(std::true_type{});
     // (the counter hands every tile index out once, so a workgroup can never run more than my_tiles tiles: the explicit bound is
     // the exit condition every wave reaches whatever the queue words hold)
-    for (int done = 1; done < my_tiles && c_cur < my_tiles; ++done) tile(std::false_type{});
+    for (int done = 1; done < my_tiles && (unsigned)c_cur < (unsigned)my_tiles; ++done) tile(std::false_type{});
     // the last tile's image
     static_for<NPIECE>([&](auto t) __attribute__((always_inline)) {
         constexpr int p = decltype(t)::value;

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void head_fused_kernel(HeadArgs a, int mt) 
     }
     __syncthreads();
     int c_cur = __builtin_amdgcn_readfirstlane(qword[0]), c_nxt = __builtin_amdgcn_readfirstlane(qword[2]);
-    if (c_cur >= mt) return;
+    if ((unsigned)c_cur >= (unsigned)mt) return;   // (queue indices are compared unsigned: no word that is not a tile index passes)
 
     // ---- weight fragments: lane (fr, fh) holds W[32 wave + fr][16 kb + 8 fh .. + 8] of each of the three planes
     f16x8 w1a[NKB1], w1b[NKB1], w1c[NPROD == 4 ? NKB1 : 1], w2a[NKB2], w2b[NKB2], w2c[NPROD == 4 ? NKB2 : 1];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void head_fused_kernel(HeadArgs a, int mt) 
         __builtin_amdgcn_global_load_lds((gptr_t)(src_plane + slab + poff), (lptr_t)(img), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(src_plane + slab + poff + 512), (lptr_t)(img + 512), 16, 0, 0);
     };
-    auto clampc = [&](int c, int fallback) { return c < mt ? c : fallback; };
+    auto clampc = [&](int c, int fallback) { return (unsigned)c < (unsigned)mt ? c : fallback; };
 
     // fragment reads (inline asm, hand-counted lgkmcnt: see gemm_f16p_ws.hip): lane (fr, fh) of row block i reads row 32 i + fr, chunk
     // fh ^ ((fr >> 3) & 1) of a slab
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void head_fused_kernel(HeadArgs a, int mt) 
         // the next tile's step-0 fragments were read during the last step of layer 1 (set NKS & 1 = 0): still in registers
     };
     tile();
-    for (int done = 1; done < mt && c_cur < mt; ++done) tile();
+    for (int done = 1; done < mt && (unsigned)c_cur < (unsigned)mt; ++done) tile();
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): no LDS-DMA may be in flight when the LDS is handed on
 }
 

@@ -47,7 +47,11 @@ struct ChunkPlan {
     std::vector<int> bound;   // chunk i = frames [bound[i], bound[i + 1]) of the forward pass, [T - bound[i + 1], T - bound[i]) of the backward pass
     int *d_list = nullptr;
     std::vector<int> off[2], len[2];
+    unsigned long long last_use = 0;   // stamp of the context's use counter: the least recently used plan is evicted (MAX_CHUNK_PLANS)
+    bool pinned = false;               // handed to a stream capture: a graph may replay launches that read d_list, so it is never evicted
 };
+constexpr size_t MAX_CHUNK_PLANS = 16;      // distinct (batch, T) shapes whose row-tile lists stay on the device
+constexpr int SIDE_RETRY_AFTER = 256;       // calls after which a caller stream that found no concurrent side stream is probed again
 
 struct StreamCounters { int64_t n_samples = 0, n_frames = 0, n_steps = 0; };
 struct StreamState { float *h = nullptr, *c = nullptr; size_t layer_stride = 0; };
@@ -92,7 +96,9 @@ struct uvad_ctx {
     hipStream_t side = nullptr;            // the library's own stream for the chunk projections
     hipStream_t side_for = nullptr;        // the caller stream `side` was PROVEN concurrent with (nullptr: not yet probed / not concurrent)
     bool side_probed_for_null = false;     // (a null caller stream is a valid key: remember that it was probed)
-    std::set<hipStream_t> side_failed;     // caller streams no side stream was found concurrent with (not probed again)
+    std::map<hipStream_t, int> side_failed;   // caller streams no side stream was found concurrent with -> calls left until the next probe
+                                              // (a probe that ran while other contexts kept the GPU busy can read "serialised" falsely)
+    unsigned long long plan_clock = 0;
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_chunk;
     std::map<std::tuple<int, int, int, int>, ChunkPlan> chunk_plans;   // (tiles, T, dirs, chunks) -> row-tile lists on the device
@@ -796,7 +802,13 @@ static bool side_stream_for(uvad_ctx *c, hipStream_t s) {
     if (c->side && c->side_for == s && (s != nullptr || c->side_probed_for_null)) return true;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
-    if (c->side_failed.count(s)) return false;
+    {
+        auto f = c->side_failed.find(s);
+        if (f != c->side_failed.end()) {
+            if (--f->second > 0) return false;
+            c->side_failed.erase(f);   // the verdict has expired: probe again
+        }
+    }
     // A stream that turns out to share s's hardware queue is kept alive until the search ends: destroyed at once, its queue would be
     // the least loaded one again and the next stream created would land on it too.
     std::vector<hipStream_t> same_queue;
@@ -818,17 +830,35 @@ static bool side_stream_for(uvad_ctx *c, hipStream_t s) {
     }
     for (hipStream_t q : same_queue) (void)hipStreamDestroy(q);
     if (found) return true;
-    c->side_failed.insert(s);
+    c->side_failed[s] = SIDE_RETRY_AFTER;
     return false;
 }
 
 static const ChunkPlan *chunk_plan(uvad_ctx *c, int tiles, int T, int D, int chunks, hipStream_t s) {
     const auto key = std::make_tuple(tiles, T, D, chunks);
     auto it = c->chunk_plans.find(key);
-    if (it != c->chunk_plans.end()) return &it->second;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;   // (allocates and copies)
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) return nullptr;
+    if (it != c->chunk_plans.end()) {
+        it->second.last_use = ++c->plan_clock;
+        if (cs != hipStreamCaptureStatusNone) it->second.pinned = true;
+        return &it->second;
+    }
+    if (cs != hipStreamCaptureStatusNone) return nullptr;   // (a new plan allocates and copies: not inside a capture)
+    if (c->chunk_plans.size() >= MAX_CHUNK_PLANS) {   // a caller that walks through many shapes: drop the least recently used list
+        auto old = c->chunk_plans.end();
+        for (auto j = c->chunk_plans.begin(); j != c->chunk_plans.end(); ++j)
+            if (!j->second.pinned && (old == c->chunk_plans.end() || j->second.last_use < old->second.last_use)) old = j;
+        if (old != c->chunk_plans.end()) {
+            // eager launches that read the list may still be in flight: drain the device before the memory goes back (this path
+            // already costs an allocation and a blocking copy); lists a graph captured stay (pinned)
+            if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+            (void)hipFree(old->second.d_list);
+            c->chunk_plans.erase(old);
+        }
+    }
     ChunkPlan P;
+    P.last_use = ++c->plan_clock;
     // Chunk lengths grow geometrically (x 1.3): only chunk 0's projection is exposed, so it is the short one, and projection i + 1 --
     // on the CUs the recurrence leaves free, about half the chip -- still finishes inside recurrence i (per frame a projection on
     // half the chip takes ~2/3 of the recurrence's time: the ratio of consecutive lengths has to stay below ~1.5; 1.0 / 1.15 / 1.3 /

@@ -111,6 +111,26 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def all_gather_floats(values, device=None):
+    """Every rank contributes a short list of floats; every rank gets the list of all ranks' lists (rank order).  One all_gather
+    (RCCL on device tensors, gloo on host tensors); [values] without a process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [list(values)]
+    on_gpu = dist.get_backend() == "nccl"
+    dev = (device if device is not None else torch.device("cuda", torch.cuda.current_device())) if on_gpu else "cpu"
+    t = torch.tensor(list(values), dtype=torch.float64, device=dev)
+    bufs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(bufs, t)
+    return [b.cpu().tolist() for b in bufs]
+
+
+def backend_name() -> str:
+    if not (dist.is_available() and dist.is_initialized()):
+        return "none (single process)"
+    b = dist.get_backend()
+    return "nccl (RCCL)" if b == "nccl" else b
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized():
         if dist.get_backend() == "nccl":
