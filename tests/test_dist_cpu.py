@@ -45,28 +45,43 @@ def _worker(rank, world, port, n_total, q):
         assert got2.shape[0] == len(idx) and (len(idx) == 0 or (got2.data_ptr() == buf.data_ptr() and torch.equal(got2.to(local.dtype), local)))
     full = udist.gather_rows(local, n_total, r, w)
     t = udist.max_over_ranks(float(r + 1))
+    # bench.py's per-rank report: every rank sees every rank's row, in rank order
+    seen = udist.all_gather_floats([float(r), float(len(idx)), 0.5 * r])
+    assert seen == [[float(k), float(udist.shard_count(n_total, k, w)), 0.5 * k] for k in range(w)], seen
+    assert udist.backend_name() == "gloo"
     udist.barrier()
     if r == 0:
         q.put((full.numpy(), t))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [7, 8, 1])
-def test_shard_gather_world2(n_total):
+def _run_world(world, n_total):
     from uvad_amd.synth import synth_pcm
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
     for p in procs:
         p.start()
-    full, tmax = q.get(timeout=120)
+    full, tmax = q.get(timeout=300)
     for p in procs:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
     want = np.stack([np.abs(synth_pcm(1, 480, seed=1000, first=i)[0]).reshape(3, 160).mean(1) for i in range(n_total)])
-    assert np.array_equal(full, want.astype(np.float32))      # 2-way result == 1-way result, bit for bit
-    assert tmax == 2.0
+    assert np.array_equal(full, want.astype(np.float32))      # n-way result == 1-way result, bit for bit
+    assert tmax == float(world)
+
+
+@pytest.mark.parametrize("n_total", [7, 8, 1])
+def test_shard_gather_world2(n_total):
+    _run_world(2, n_total)
+
+
+def test_shard_scatter_gather_world8_uneven_4099_rows():
+    """The driver's scaling run is N = 8: eight gloo ranks here (RCCL needs the node), cfg 4's batch of 4 096 utterances plus 3 so that
+    the shards are uneven (three ranks own 513 rows, five 512): scatter from the root (both forms, twice into one receive buffer),
+    gather back, the per-rank all-gather of bench.py's `ranks` object, max over ranks -- every row bit-identical to the unsharded run."""
+    _run_world(8, 4096 + 3)
 
 
 def test_shard_indices_partition():

@@ -349,7 +349,8 @@ def test_weight_stationary_projection_is_bit_identical_to_the_streaming_kernel(F
 
 @pytest.mark.parametrize("F,lstm,B,T", [(64, None, 256, 1000),                       # cfg 2
                                         (80, None, 37, 611),                         # K = 96, rows that straddle sequence tiles everywhere
-                                        (64, {"hidden_size": 64}, 61, 509),          # N = 512
+                                        (64, {"hidden_size": 64}, 61, 509),          # N = 512 (lowered to one chunk by the launch-size rule)
+                                        (64, {"hidden_size": 64}, 256, 1000),        # N = 512 large enough to STAY chunked: lstm_rec_kernel<64, ...> with carried state
                                         (60, {"bidirectional": False}, 130, 300)])   # one direction
 def test_time_chunked_layers_are_bit_identical_to_one_launch_per_layer(F, lstm, B, T):
     """uvad_set_time_chunks: a layer cut into n time chunks -- the projection of chunk i + 1 (weight-stationary GEMM over the row tiles

@@ -66,6 +66,11 @@ class ForwardPipeline:
                 r.load_state_dict(model.state_dict())
                 if recurrent_tile:
                     r.set_recurrent_tile(recurrent_tile)
+                if self.depth > 1:
+                    # time-chunked layers were designed and measured for ONE batch alone on the GPU (its side stream takes the CUs the
+                    # recurrence leaves idle); with several steps in flight those CUs belong to the other slots, and a slot's first
+                    # submit would run the side-stream probe beside busy neighbours.  One launch per layer here.
+                    r.set_time_chunks(1)
             self.select_streams()
         except Exception:
             self.close()
