@@ -23,6 +23,7 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 1e-4
 REL = 1.5
+WORST_FRAME_CAP = 1.5e-3     # x4 network, pinned draw (see test_cfg2_full_size_logit_parity): absolute cap on the worst of 256 000 frames
 
 
 def _cfg2_model(dev, scale):
@@ -130,13 +131,15 @@ def test_cfg2_full_size_logit_parity(scale):
             if mode != "f16p3":
                 assert st["p99.9"] < LOGIT_TOL, (mode, tile, "p99.9 vs f64", st["p99.9"])
                 assert st["rms"] < 0.1 * LOGIT_TOL, (mode, tile, "rms vs f64", st["rms"])
-            # The single worst of 256 000 frames is the one statistic here that depends on the draw.  This test's input is the feature
-            # kernel's output, and when a change of that kernel (round 4: framing loads) moved the features' last bits, the fp32 CPU
-            # path's OWN worst frame went from 6.4e-4 to 1.14e-3 (default mode: 1.04e-3 with the 4-sequence recurrence, 1.31e-3 with the
-            # 16-sequence one; every bulk statistic below the CPU path's).  The 1e-3 cap the default mode carried since round 2 was a
-            # number fitted to one draw -- the reference arithmetic itself does not meet it on this one -- so the worst frame is now
-            # bounded through the CPU path (<= REL x its worst frame, above) and by the 3e-3 sanity cap the other modes always had.
-            assert st["max"] < 3.0e-3 and st_cpu["max"] < 3.0e-3, (mode, tile, "absolute max vs f64", st["max"], st_cpu["max"])
+            # The single worst of 256 000 frames.  Up to round 4 this test's input was the feature kernel's output, so every edit of that
+            # kernel re-drew the heavy tail and the cap followed twice (1e-3 -> 3e-3).  The input is now fixed (_cfg2_features: the float64
+            # oracle's features, no kernel under edit produces them), so the cap is PINNED on that draw (round 5, first run on the fixed
+            # input): the fp32 CPU path's own worst frame is 8.4e-4, the default mode's 9.2e-4 (4-sequence recurrence) / 1.06e-3
+            # (16-sequence); WORST_FRAME_CAP = 1.5e-3 holds for the reference arithmetic itself and for the default mode with either
+            # recurrent form.  It moves only if the CLASSIFIER's arithmetic is changed on purpose -- never for a feature-kernel edit.
+            # The non-default modes (exact-f32 1.19e-3, three-product 1.34e-3 on this draw) keep the 3e-3 sanity cap they always had.
+            assert st_cpu["max"] < WORST_FRAME_CAP, ("the reference's fp32 CPU path on the pinned draw", st_cpu["max"])
+            assert st["max"] < (WORST_FRAME_CAP if mode == "f16p" else 3.0e-3), (mode, tile, "absolute max vs f64", st["max"])
     rt.set_gemm_mode("f16p")
     rt.set_recurrent_tile(0)
 
