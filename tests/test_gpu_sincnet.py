@@ -62,20 +62,33 @@ def test_sincnet_features_match_oracle(B, S):
 
 
 def test_pyannet_forward_matches_oracle_and_5s_cut_gives_293_frames():
-    from oracle import torch_ref as tr
-    front, cls, m = _pair()
+    """PyanNet.forward (PyanNet.py:162-195) on 4 cuts of 5 s.  The north-star bound (1e-4 max-abs vs the CPU path) is held on the
+    contractive x2 classifier; on the near-chaotic x4 classifier (tests/test_gpu_scale.py) a last-bit difference of the SincNet features is
+    amplified to ~1e-4 at some frame by ANY two fp32 evaluations (rounds 1-4 sat at 6e-5 .. 1.3e-4 on single draws), so there the GPU is
+    measured against the float64 evaluation of the same network and may be no further from it than the fp32 CPU path (rms x 1.5, worst
+    frame x 3: 1 172 frames are few).  The at-size form of this test is test_pyannet_cfg_size_logit_parity."""
+    from oracle import torch_ref as tr, parity_stats as ps
     wav = torch.from_numpy(tr.synth_pcm(4, 80000, seed=5))
-    feats = front(wav.unsqueeze(1)).transpose(1, 2).contiguous()
-    want_logits, want_probs = cls(feats)
-    logits, probs = m.forward_logits(wav.cuda().unsqueeze(1))
-    torch.cuda.synchronize()
-    assert logits.shape == (4, 293)
-    err = (logits.cpu() - want_logits).abs().max().item()
-    perr = (probs.cpu() - want_probs).abs().max().item()
-    print(f"PyanNet 4 x 5 s: max-abs logit err {err:.2e} prob err {perr:.2e} (logit range {want_logits.min():.2f}..{want_logits.max():.2f})")
-    assert err < LOGIT_TOL and perr < LOGIT_TOL
-    out = m(wav.cuda().unsqueeze(1))
-    assert out.shape == (4, 293, 1) and torch.equal(out.squeeze(-1), probs)
+    for scale in (2.0, 4.0):
+        front, cls, m = _pair(scale=scale)
+        feats = front(wav.unsqueeze(1)).transpose(1, 2).contiguous()
+        want_logits, want_probs = cls(feats)
+        logits, probs = m.forward_logits(wav.cuda().unsqueeze(1))
+        torch.cuda.synchronize()
+        assert logits.shape == (4, 293)
+        err = (logits.cpu() - want_logits).abs().max().item()
+        perr = (probs.cpu() - want_probs).abs().max().item()
+        print(f"PyanNet 4 x 5 s, classifier x{scale:g}: max-abs logit err {err:.2e} prob err {perr:.2e} (logit range {want_logits.min():.2f}..{want_logits.max():.2f})")
+        if scale == 2.0:
+            assert err < LOGIT_TOL and perr < LOGIT_TOL
+        else:
+            truth = ps.truth_logits(cls.state_dict(), ps.truth_sincnet(front, wav), 60)
+            sg, sc = ps.error_stats(logits.cpu().numpy(), truth), ps.error_stats(want_logits.numpy(), truth)
+            print("  " + ps.fmt("GPU vs f64", sg) + "\n  " + ps.fmt("CPU fp32 vs f64", sc))
+            assert sg["rms"] <= 1.5 * sc["rms"] and sg["max"] <= max(LOGIT_TOL, 3.0 * sc["max"]), (sg, sc)
+            assert perr < LOGIT_TOL
+        out = m(wav.cuda().unsqueeze(1))
+        assert out.shape == (4, 293, 1) and torch.equal(out.squeeze(-1), probs)
 
 
 REL = 1.5

@@ -14,7 +14,13 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--seconds", type=float, default=5.0)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--check", type=int, default=4, help="utterances compared with the CPU oracle (0 = skip)")
+ap.add_argument("--lib", default=None, help="another build of libuvad.so (A/B on one box)")
+ap.add_argument("--mode", default="f16p", help="GEMM mode: f16p (split-f16 SincNet stages) or f32 (the exact-f32 stages of sincnet.hip)")
+ap.add_argument("--stages", action="store_true", help="per-kernel durations of one uvad_sincnet call (torch profiler, device time)")
 args = ap.parse_args()
+if args.lib:
+    from uvad_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(args.lib)
 dev = torch.device("cuda:0")
 B, S = args.batch, int(args.seconds * 16000)
 torch.manual_seed(1234)   # the SincNet convolutions keep torch's default initialisation: seeded, so that two runs time and check the same network
@@ -23,6 +29,7 @@ m.build()
 seed_weights(m, 1234, 4.0)   # classifier only; the SincNet front end keeps its mel-spaced initialisation
 m = m.to(dev).eval()
 rt = m.runtime(dev)
+rt.set_gemm_mode(args.mode)
 wav = synth_pcm_device(B, S, 1000, dev)
 T = rt.sincnet_num_frames(S)
 
@@ -44,6 +51,18 @@ flop = 2.0 * (L1 * 80 * 251 + L2 * 60 * 400 + L3 * 60 * 300) * B
 out = {"config": f"PyanNet, B={B} x {args.seconds:g} s ({T} frames each), synthetic PCM, default-init SincNet + seeded x4 classifier",
        "sincnet_ms": ms_front, "sincnet_TFLOPs_f32": flop / ms_front / 1e9, "frac_of_157.3_TFLOPs": flop / ms_front / 1e9 / 157.3,
        "forward_wav_ms": ms_all, "frames_per_s": B * T / ms_all * 1e3, "audio_seconds_per_s": B * args.seconds / ms_all * 1e3}
+out["gemm_mode"] = args.mode
+if args.stages:
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(5):
+            rt.sincnet(wav)
+        torch.cuda.synchronize()
+    st = {}
+    for e in prof.key_averages():
+        if "uvad" in e.key:
+            st[e.key.split("(")[0].replace("void uvad::(anonymous namespace)::", "").replace("uvad::(anonymous namespace)::", "")] = round(e.device_time_total / e.count / 1e3, 4)
+    out["stage_ms"] = st
 if args.check:
     from oracle import torch_ref as tr
     front = tr.TorchSincNet().eval()

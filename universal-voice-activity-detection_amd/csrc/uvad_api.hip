@@ -83,6 +83,12 @@ struct uvad_ctx {
     float *sn_wav_g = nullptr, *sn_wav_b = nullptr;
     float *sn_wt[3] = {nullptr, nullptr, nullptr}, *sn_bias[3] = {nullptr, nullptr, nullptr};
     float *sn_g[3] = {nullptr, nullptr, nullptr}, *sn_b[3] = {nullptr, nullptr, nullptr};
+    // ... and for the split-f16 form of the stages (sincnet_f16p.hip; GEMM modes 1 / 3): B-operand register images, 2^-S, padded biases,
+    // and the largest |gamma| / |beta| of the norm in FRONT of each stage (the f16 range guard of sincnet_impl)
+    bool sinc_f16 = false, sinc_f16_used = false;   // packed and usable / what the most recent uvad_sincnet ran
+    unsigned short *sn_wfrag[3] = {nullptr, nullptr, nullptr};
+    float sn_wscale[3] = {1.f, 1.f, 1.f}, *sn_bias16[3] = {nullptr, nullptr, nullptr};
+    float sn_in_gmax[3] = {0.f, 0.f, 0.f}, sn_in_bmax[3] = {0.f, 0.f, 0.f};
     std::vector<void *> allocs;          // feature tables, twiddles: live as long as the context
     std::vector<void *> weight_allocs;   // everything uvad_finalize uploads: replaced by the next uvad_finalize
     // timing
@@ -166,6 +172,7 @@ struct SincLayout {
     int Cin[3], Cout[3], Kw[3], stride[3], NW[3], pt[3], phases[3];
     int64_t Lin[3], Lconv[3], Lpool[3];
     int ntiles[3];
+    bool f16 = false; int cst[3] = {0, 0, 0}, ntiles16[3] = {0, 0, 0};   // split-f16 form (sincnet_f16p.hip): floats per output row, tiles of 64 pooled outputs
     size_t off_s0 = 0, off_P[3] = {0, 0, 0}, off_part[3] = {0, 0, 0}, off_sc[3] = {0, 0, 0}, total = 0;
     bool ok = false;
 };
@@ -191,11 +198,21 @@ SincLayout sinc_carve(const uvad_ctx *c, int B, int64_t S) {
         if (l.Lpool[i] <= 0) l.ok = false;
         L = l.Lpool[i];
     }
+    l.f16 = sinc_f16p_supported(q.n_filters, q.kernel_size, q.stride, q.c2, q.k2, q.c3, q.k3);
     size_t o = 0;
     l.off_s0 = o; o += align_up((size_t)2 * B * sizeof(float));
     for (int i = 0; i < 3; ++i) {
-        l.off_P[i] = o; o += align_up((size_t)B * l.Cout[i] * (size_t)(l.ok ? l.Lpool[i] : 0) * sizeof(float));
-        l.off_part[i] = o; o += align_up((size_t)B * (size_t)(l.ok ? l.ntiles[i] : 0) * l.phases[i] * l.NW[i] * 2 * sizeof(float));
+        // the buffers are sized for whichever form a call runs (the GEMM mode can change between calls)
+        size_t pooled = (size_t)B * l.Cout[i] * (size_t)(l.ok ? l.Lpool[i] : 0);
+        size_t part = (size_t)B * (size_t)(l.ok ? l.ntiles[i] : 0) * l.phases[i] * l.NW[i] * 2;
+        if (l.f16) {
+            l.cst[i] = sinc_f16p_cst(i);
+            l.ntiles16[i] = l.ok ? sinc_f16p_ntiles(l.Lpool[i]) : 0;
+            pooled = std::max(pooled, (size_t)B * l.cst[i] * (size_t)(l.ok ? l.Lpool[i] : 0));
+            part = std::max(part, sinc_f16p_partial_floats(i, B, l.ntiles16[i]));
+        }
+        l.off_P[i] = o; o += align_up(pooled * sizeof(float));
+        l.off_part[i] = o; o += align_up(part * sizeof(float));
         l.off_sc[i] = o; o += align_up((size_t)2 * B * l.Cout[i] * sizeof(float));
     }
     l.total = o;
@@ -403,8 +420,11 @@ void free_weights(uvad_ctx *c) {
     c->lin_w.clear(); c->lin_b.clear(); c->lin_w_split16.clear(); c->lin_w_scale.clear();
     c->cls_w = c->cls_b = nullptr;
     c->sn_wav_g = c->sn_wav_b = nullptr;
-    for (int i = 0; i < 3; ++i) c->sn_wt[i] = c->sn_bias[i] = c->sn_g[i] = c->sn_b[i] = nullptr;
-    c->sinc_ready = false;
+    for (int i = 0; i < 3; ++i) {
+        c->sn_wt[i] = c->sn_bias[i] = c->sn_g[i] = c->sn_b[i] = c->sn_bias16[i] = nullptr;
+        c->sn_wfrag[i] = nullptr;
+    }
+    c->sinc_ready = c->sinc_f16 = false;
     c->finalized = false;
 }
 }  // namespace
@@ -562,6 +582,36 @@ int uvad_finalize(uvad_ctx *c) {
             if ((r = dev_upload(c, bias.data(), bias.size(), &c->sn_bias[i], true))) return r;
             if ((r = dev_upload(c, g->data.data(), g->data.size(), &c->sn_g[i], true))) return r;
             if ((r = dev_upload(c, be->data.data(), be->data.size(), &c->sn_b[i], true))) return r;
+            // the norm in FRONT of stage i + 1 (stage 0's is the waveform norm): bounds for the f16 range guard
+            if (i < 2) {
+                float gm = 0.f, bm = 0.f;
+                for (float v : g->data) gm = std::max(gm, std::fabs(v));
+                for (float v : be->data) bm = std::max(bm, std::fabs(v));
+                c->sn_in_gmax[i + 1] = gm; c->sn_in_bmax[i + 1] = bm;
+            }
+        }
+        c->sn_in_gmax[0] = std::fabs(wg->data[0]); c->sn_in_bmax[0] = std::fabs(wb->data[0]);
+        // the split-f16 form of the stages (sincnet_f16p.hip): W[n][k] in the stage's K order -> three exact f16 planes as register images
+        c->sinc_f16 = sinc_f16p_supported(q.n_filters, q.kernel_size, q.stride, q.c2, q.k2, q.c3, q.k3);
+        for (int i = 0; i < 3 && c->sinc_f16; ++i) {
+            const std::string id = std::to_string(i);
+            const HostTensor *w = get(i == 0 ? std::string("sincnet.conv1d.0.filters") : "sincnet.conv1d." + id + ".weight");
+            const HostTensor *b = i == 0 ? nullptr : get("sincnet.conv1d." + id + ".bias");
+            const int ldk = 32 * sinc_f16p_ksteps(i), cst = sinc_f16p_cst(i);
+            const int cpad = i == 1 ? cin[1] : 64;            // k = tap * cpad + channel (stage 1: 80 channels per tap, stage 2: 64 with 60 real)
+            std::vector<float> wn((size_t)cout[i] * ldk, 0.0f), bias((size_t)cst, 0.0f);
+            for (int n = 0; n < cout[i]; ++n) {
+                if (i == 0)
+                    for (int t = 0; t < kw[0]; ++t) wn[(size_t)n * ldk + t] = w->data[(size_t)n * kw[0] + t];
+                else
+                    for (int ci = 0; ci < cin[i]; ++ci)
+                        for (int t = 0; t < kw[i]; ++t) wn[(size_t)n * ldk + t * cpad + ci] = w->data[((size_t)n * cin[i] + ci) * kw[i] + t];
+                if (b) bias[n] = b->data[n];
+            }
+            std::vector<unsigned short> frag(sinc_f16p_wfrag_elems(i));
+            if (!sinc_f16p_pack_weights(i, wn.data(), cout[i], ldk, frag.data(), &c->sn_wscale[i])) { c->sinc_f16 = false; break; }   // a non-finite weight: exact kernels
+            if ((r = dev_upload(c, frag.data(), frag.size(), &c->sn_wfrag[i], true))) return r;
+            if ((r = dev_upload(c, bias.data(), bias.size(), &c->sn_bias16[i], true))) return r;
         }
         c->sinc_ready = true;
     }
@@ -620,6 +670,31 @@ static int sincnet_impl(uvad_ctx *c, const float *d_wav, int B, int64_t S, float
     float *s0 = reinterpret_cast<float *>(base + l.off_s0);
     HIPCHK(c, launch_wav_stats(d_wav, B, S, S, c->sn_wav_g, c->sn_wav_b, q.eps, s0, s0 + B, s));
     const float *in = d_wav, *in_scale = s0, *in_shift = s0 + B;
+    // Split-f16 form (GEMM modes 1 / 3) when the geometry is the reference's and every stage input provably fits the f16 range: an
+    // instance-normalised value is at most sqrt(L - 1) in magnitude, so |gamma| * sqrt(L) + |beta| bounds what the staging converts.
+    bool f16 = l.f16 && c->sinc_f16 && (c->gemm_mode == 1 || c->gemm_mode == 3);
+    for (int i = 0; i < 3 && f16; ++i)
+        if (!(c->sn_in_gmax[i] * std::sqrt((double)l.Lin[i]) + c->sn_in_bmax[i] < 60000.0)) f16 = false;
+    c->sinc_f16_used = f16;
+    if (f16) {
+        for (int i = 0; i < 3; ++i) {
+            float *P = reinterpret_cast<float *>(base + l.off_P[i]);
+            float *part = reinterpret_cast<float *>(base + l.off_part[i]);
+            float *sc = reinterpret_cast<float *>(base + l.off_sc[i]);
+            SincF16Args a{};
+            a.in = in; a.in_bstride = S; a.Lin = (int)l.Lin[i];
+            a.in_scale = in_scale; a.in_shift = in_shift; a.n_in = l.Cin[i]; a.slope = q.leaky_slope;
+            a.Wfrag = c->sn_wfrag[i]; a.wscale = c->sn_wscale[i]; a.bias = c->sn_bias16[i];
+            a.Lpool = (int)l.Lpool[i]; a.ntiles = l.ntiles16[i];
+            a.out = P; a.partials = part; a.B = B; a.n_cu = c->n_cu;
+            HIPCHK(c, launch_sinc_conv_f16p(i, a, s));
+            HIPCHK(c, launch_norm_finalize_f16p(i, part, B, l.ntiles16[i], l.Cout[i], (int)l.Lpool[i], c->sn_g[i], c->sn_b[i], q.eps, sc,
+                                                sc + (size_t)B * l.Cout[i], s));
+            in = P; in_scale = sc; in_shift = sc + (size_t)B * l.Cout[i];
+        }
+        HIPCHK(c, launch_sinc_out_f16p(in, in_scale, in_shift, B, l.Cout[2], l.cst[2], (int)l.Lpool[2], q.leaky_slope, d_feats, l.Cout[2], s));
+        return UVAD_OK;
+    }
     for (int i = 0; i < 3; ++i) {
         float *P = reinterpret_cast<float *>(base + l.off_P[i]);
         float *part = reinterpret_cast<float *>(base + l.off_part[i]);

@@ -264,4 +264,30 @@ hipError_t launch_norm_finalize(const float *partials, int B, int ntiles, int pt
 hipError_t launch_sinc_out(const float *P, const float *scale, const float *shift, int B, int C, int L, float slope, float *feats, int ldf,
                            hipStream_t s);
 
+// ---- sincnet_f16p.hip: the same three stages on the f16 matrix cores (f32-equivalent split arithmetic), channel-minor intermediates ----
+struct SincF16Args {
+    const float *in; long long in_bstride; int Lin;        // stage 0: in[b * in_bstride + x] (the waveform); stages 1, 2: in[(b * Lin + x) * cst_in + c]
+    const float *in_scale, *in_shift; int n_in;            // [B][n_in]: x * scale + shift applied while staging (n_in = 1, or the real channel count)
+    float slope;                                           // leaky_relu of the previous stage (stages 1, 2)
+    const unsigned short *Wfrag; float wscale;             // sinc_f16p_pack_weights
+    const float *bias;                                     // [cst] zero padded
+    int Lpool, ntiles;                                     // ntiles = sinc_f16p_ntiles(Lpool)
+    float *out;                                            // [B][Lpool][cst] pooled, before the norm (channels past Cout written as zero)
+    float *partials;                                       // [B][ntiles][4 slots][3][cst]: (count, sum, M2 about the set's own mean); slot 0 per tile,
+                                                           // stage 0's channels 64 .. 79 one slot per wave
+    int B, n_cu;
+};
+bool sinc_f16p_supported(int n_filters, int kernel_size, int stride, int c2, int k2, int c3, int k3);
+int sinc_f16p_ksteps(int stage);       // 32-deep k-steps of the stage's contraction (K = 32 * ksteps: the packed weight row length)
+int sinc_f16p_cst(int stage);          // floats per output row (channels padded to whole 16-channel tiles)
+int sinc_f16p_ntiles(long long Lpool);
+size_t sinc_f16p_partial_floats(int stage, int B, int ntiles);
+size_t sinc_f16p_wfrag_elems(int stage);
+bool sinc_f16p_pack_weights(int stage, const float *w, int nrows, int ldk, unsigned short *out, float *wscale);
+hipError_t launch_sinc_conv_f16p(int stage, const SincF16Args &a, hipStream_t s);
+hipError_t launch_norm_finalize_f16p(int stage, const float *partials, int B, int ntiles, int C, int L, const float *gamma, const float *beta, float eps,
+                                     float *scale, float *shift, hipStream_t s);
+hipError_t launch_sinc_out_f16p(const float *P, const float *scale, const float *shift, int B, int C, int CST, int L, float slope, float *feats, int ldf,
+                                hipStream_t s);
+
 }  // namespace uvad
