@@ -242,8 +242,17 @@ int uvad_forward_wav(uvad_ctx *, const float *d_wav, int B, int64_t S, float *d_
  *      network twice mode 1's distance from the float64 truth (a rounded weight is a slightly different network), which is why
  *      it is not the default.  Small launches (streaming steps) run mode 1's kernels: outputs of different launch sizes then
  *      differ in the last bits.
+ * The SincNet front end (uvad_sincnet, uvad_forward_wav) follows the same selector: modes 1 and 3 run its three convolution stages on
+ * the f16 matrix cores with the split arithmetic of mode 1 (exact three-plane weights in registers, sincnet_f16p.hip) when the geometry
+ * is the reference's (sinc bank of 80 filters x <= 256 taps at stride 10; Conv1d(80 -> <= 64, 5); Conv1d(<= 64 -> <= 64, 5)) and every
+ * stage input provably fits the f16 range (|gamma| * sqrt(length) + |beta| < 60000 for the instance norm in front of it); modes 0 and 2,
+ * other geometries and inputs outside that bound run the exact-f32 stages (v_mfma_f32_32x32x2_f32, sincnet.hip).  uvad_get_sincnet_form
+ * tells which.
  * All are held to the same 1e-4 logit bound by the tests.  Replaces nothing in the reference (torch picks its GEMM). */
 int uvad_set_gemm_mode(uvad_ctx *, int mode);
+/* What the most recent uvad_sincnet / uvad_forward_wav call of this context ran: 1 = the split-f16 stages, 0 = the exact-f32 stages
+ * (also before the first call); negative on error. */
+int uvad_get_sincnet_form(const uvad_ctx *);
 
 /* How many sequences one recurrent workgroup owns (the time loop of nn.LSTM, PyanNet2.py:169-172):
  *   4   latency form (v_mfma_f32_4x4x1): B/4 x directions workgroups, the right one up to a few hundred sequences;

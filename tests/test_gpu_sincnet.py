@@ -147,6 +147,55 @@ def test_pyannet_cfg_size_logit_parity(scale):
         assert sg["p99.9"] < 3e-4 and sg["rms"] < 5e-5, sg
 
 
+def test_sincnet_split_f16_stages_against_the_exact_f32_stages_and_the_float64_truth():
+    """The default GEMM mode runs the SincNet stages on the f16 matrix cores (sincnet_f16p.hip: exact three-plane weights, 22-bit activations,
+    f32 accumulation); mode "f32" runs the exact-f32 stages of sincnet.hip (v_mfma_f32_32x32x2_f32).  Ragged lengths around the 64-pooled-output
+    tiles of the new kernels (stage tiles end at 192 / 64 conv / pooled positions), both forms against the float64 evaluation: the split-f16
+    form may be no further from it than 1.5 x the exact-f32 form on rms, and both within FEAT_TOL at the worst value (outputs of >= 8 frames)."""
+    from oracle import torch_ref as tr, parity_stats as ps
+    front, _, m = _pair(seed=321)
+    rt = m.runtime(torch.device("cuda:0"))
+    rng = np.random.default_rng(12)
+    for S in (80000, 1261 + 270 * 7, 10 * 191 * 3 + 251 + 3, 19451, 57731, 160000):
+        B = int(rng.integers(1, 6))
+        wav = torch.from_numpy(tr.synth_pcm(B, S, seed=int(rng.integers(0, 10000))))
+        truth = ps.truth_sincnet(front, wav).numpy()
+        rt.set_gemm_mode("f16p")
+        g16 = rt.sincnet(wav.cuda()).cpu().numpy().astype(np.float64)
+        assert rt.sincnet_form() == "f16p"
+        rt.set_gemm_mode("f32")
+        g32 = rt.sincnet(wav.cuda()).cpu().numpy().astype(np.float64)
+        assert rt.sincnet_form() == "f32"
+        rt.set_gemm_mode("f16p")
+        e16, e32 = np.abs(g16 - truth), np.abs(g32 - truth)
+        r16, r32 = float(np.sqrt((e16 ** 2).mean())), float(np.sqrt((e32 ** 2).mean()))
+        print(f"S={S} B={B} frames {truth.shape[1]}: split-f16 max {e16.max():.2e} rms {r16:.2e}; exact-f32 max {e32.max():.2e} rms {r32:.2e}; "
+              f"|f16p - f32| max {np.abs(g16 - g32).max():.2e}")
+        assert g16.shape == g32.shape == truth.shape
+        assert r16 <= 1.5 * r32 + 1e-9, (S, r16, r32)
+        if truth.shape[1] >= 8:
+            assert e16.max() < FEAT_TOL and e32.max() < FEAT_TOL, (S, e16.max(), e32.max())
+
+
+def test_sincnet_split_f16_form_is_refused_outside_the_f16_range_and_the_reference_geometry():
+    """The split-f16 stages convert instance-normalised inputs to f16: the library runs them only when |gamma| * sqrt(L) + |beta| < 60000 for
+    the norm in front of every stage (an instance-normalised value is at most sqrt(L - 1)), else the exact-f32 stages -- no flag to set, no
+    host synchronisation.  A huge affine weight on the waveform norm must therefore select the exact form and still match the oracle."""
+    from oracle import torch_ref as tr
+    front, _, m = _pair(seed=5)
+    with torch.no_grad():
+        front.wav_norm1d.weight.fill_(400.0)               # 400 * sqrt(32000) = 71 554 > 60 000
+        m.sincnet.wav_norm1d.weight.fill_(400.0)
+    rt = m.runtime(torch.device("cuda:0"))
+    wav = torch.from_numpy(tr.synth_pcm(2, 32000, seed=3))
+    got = rt.sincnet(wav.cuda()).cpu().numpy()
+    assert rt.sincnet_form() == "f32"
+    want = front(wav.unsqueeze(1)).transpose(1, 2).numpy()
+    assert np.abs(got - want).max() < FEAT_TOL
+    short = rt.sincnet(wav[:, :16000].cuda())             # 400 * sqrt(16000) = 50 596: inside the bound again
+    assert rt.sincnet_form() == "f16p" and np.abs(short.cpu().numpy() - front(wav[:, :16000].unsqueeze(1)).transpose(1, 2).numpy()).max() < FEAT_TOL
+
+
 def test_sincnet_batch_invariance_and_determinism():
     """An utterance's features do not depend on its batch neighbours or on scheduling (tile-ordered statistics)."""
     from oracle import torch_ref as tr

@@ -384,7 +384,12 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
     };
 
     const unsigned short *p2w = p2 + (size_t)(wave * 16) * 512 + lane * 8;   // fragment (rb, ks) at + (rb*4 + ks) * 512
-    const unsigned char *p2qw = reinterpret_cast<const unsigned char *>(p2) + ((size_t)(wave * 4) * 64 + lane) * 32;   // (P2Q) fragment rb at + rb * 2048
+    // (P2Q) fragment rb at + rb * 2048, 32 bytes per lane.  A lane's two 16-byte halves sit in the order that makes BOTH ds_read_b128 of the
+    // fragment bank-conflict-free: with the halves in k order, lanes l and l + 16 (+ 8 in the instruction's 16-lane groups) meet on one
+    // 16-byte slot in each read (2-way: 52 % of the kernel's LDS-active cycles were conflicts); lanes 16 .. 31 and 48 .. 63 therefore keep
+    // their SECOND half first (pack_whh16h_p2q stores it that way) and read at + 16 first.
+    const int p2q_swap = 16 * ((lane >> 4) & 1);
+    const unsigned char *p2qw = reinterpret_cast<const unsigned char *>(p2) + ((size_t)(wave * 4) * 64 + lane) * 32;
     const int hfrag = j * R16_HP + 8 * q;                                   // + 32 ks inside a plane
     const int hq_rd = j * R16_HQ + 32 * q, hq_wr = j * R16_HQ + 16 * wave + 4 * q;   // (P2Q) this lane's B fragment / the dword of its four cells
     const int p2q_scale = P2Q ? a.p2q_scale : 127;
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
         f16x8 w2n = {};
         if constexpr (NPROD == 4 && !P2Q) w2n = *reinterpret_cast<const f16x8 *>(p2w);
         auto p2q_frag = [&](int rb) {   // (P2Q) the bf8 fragment of row block rb: 32 bytes per lane
-            const u32x4 lo4 = *reinterpret_cast<const u32x4 *>(p2qw + rb * 2048), hi4 = *reinterpret_cast<const u32x4 *>(p2qw + rb * 2048 + 16);
+            const u32x4 lo4 = *reinterpret_cast<const u32x4 *>(p2qw + p2q_swap + rb * 2048), hi4 = *reinterpret_cast<const u32x4 *>(p2qw + (16 - p2q_swap) + rb * 2048);
             return i32x8{(int)lo4[0], (int)lo4[1], (int)lo4[2], (int)lo4[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
         };
         i32x8 wqn = {};
@@ -652,7 +657,8 @@ bool pack_whh16h(const float *w_hh, unsigned *regs, unsigned short *p2, float *w
     return finite;
 }
 
-// P2 (the third plane of pack_whh16h's split) as bf8 for v_mfma_scale_f32_16x16x128_f8f6f4: [wave 8][rb 4][lane 64][32 bytes]; lane
+// P2 (the third plane of pack_whh16h's split) as bf8 for v_mfma_scale_f32_16x16x128_f8f6f4: [wave 8][rb 4][lane 64][32 bytes] (the 16-byte
+// halves of lanes 16 .. 31 and 48 .. 63 swapped: see the kernel's p2q_swap); lane
 // (row = lane & 15, kq = lane >> 4) holds row -> (unit 16 wave + 4 rb + (row >> 2), gate row & 3), byte jj -> column k' = 32 kq + jj, where k'
 // names the SOURCE unit 16 (k' >> 4) + 4 (k' & 3) + ((k' >> 2) & 3) (the kernel's fp8 image of h keeps a lane's four cells in one dword).
 // E5M2 is the upper byte of an f16, so an element is exactly representable iff the low byte of (P2 x 2^13 as f16) is zero: P2 is 0, +-1 or
@@ -693,7 +699,8 @@ bool pack_whh16h_p2q(const float *w_hh, unsigned short *p2q, int *scale) {
                     unsigned short bits;
                     __builtin_memcpy(&bits, &sh, 2);
                     if ((bits & 0xffu) != 0 || (float)sh != (float)p2v * 8192.0f) exact = false;
-                    out[((size_t)((wave * 4 + rb) * 64 + lane)) * 32 + jj] = (unsigned char)(bits >> 8);
+                    // (lanes 16 .. 31 and 48 .. 63: the two 16-byte halves swapped -- the kernel's conflict-free read order)
+                    out[((size_t)((wave * 4 + rb) * 64 + lane)) * 32 + (jj ^ (16 * ((lane >> 4) & 1)))] = (unsigned char)(bits >> 8);
                 }
             }
     return exact;

@@ -1450,6 +1450,11 @@ int uvad_set_recurrent_tile(uvad_ctx *c, int sequences) {
 }
 
 int uvad_get_recurrent_tile(const uvad_ctx *c) { return c ? c->rec_tile_used : UVAD_E_ARG; }
+int uvad_get_sincnet_form(const uvad_ctx *c) {
+    if (!c) return UVAD_E_ARG;
+    return c->sinc_f16_used ? 1 : 0;
+}
+
 int uvad_get_p2_on_fp8(const uvad_ctx *c) {
     if (!c) return UVAD_E_ARG;
     if (!c->has_model || !c->finalized || c->mc.hidden != 128 || c->gemm_mode == 2) return 0;

@@ -329,6 +329,10 @@ class VadRuntime:
         """True if the 16-sequence recurrence runs its P2 x h product on the 8-bit matrix pipe (every P2 element exactly bf8: include/uvad.h)."""
         return bool(self.lib.uvad_get_p2_on_fp8(self.ctx))
 
+    def sincnet_form(self) -> str:
+        """What the most recent sincnet() / forward_wav() ran: "f16p" (the split-f16 stages of sincnet_f16p.hip) or "f32" (sincnet.hip)."""
+        return "f16p" if int(self.lib.uvad_get_sincnet_form(self.ctx)) == 1 else "f32"
+
     def set_time_chunks(self, chunks: int):
         """Time chunks per layer for a batch that runs alone (include/uvad.h): 0 = automatic (default), 1 = off, n = that many.  The
         projection of chunk i + 1 runs on a stream of the library's own beside the recurrence of chunk i; outputs are bit-identical."""
