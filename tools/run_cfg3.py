@@ -13,13 +13,14 @@ ap.add_argument("--streams", type=int, default=4096)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--int16", action="store_true")
+ap.add_argument("--chunk", type=int, default=16000, help="samples per stream and step (cfg 3: 1 s)")
 ap.add_argument("--lib", default=None, help="another build of libuvad.so (A/B on one box)")
 args = ap.parse_args()
 if args.lib:
     from uvad_amd import _lib
     _lib.LIB_PATH = os.path.abspath(args.lib)
 dev = torch.device("cuda:0")
-B, C, F = args.streams, 16000, 64
+B, C, F = args.streams, args.chunk, 64
 rt = uvad_amd.Fbank(uvad_amd.FbankConfig(num_filters=F, window_type="hamming"))._runtime(dev)
 g = torch.Generator(device=dev); g.manual_seed(3)
 pcm = [0.1 * torch.randn(B, C, generator=g, device=dev) for _ in range(4)]      # 4 distinct chunks, cycled
@@ -46,6 +47,6 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.reps
 frames = B * T * args.steps
 bpf = (320 if args.int16 else 640) + 4 * F
-print(json.dumps({"config": f"{B} streams x 1 s chunks x {args.steps} steps, hipGraph, fbank only, pcm {'int16' if args.int16 else 'f32'}",
+print(json.dumps({"config": f"{B} streams x {C / 16000:g} s chunks x {args.steps} steps, hipGraph, fbank only, pcm {'int16' if args.int16 else 'f32'}",
                   "frames_per_s": frames / dt, "ms_per_graph": dt * 1e3, "us_per_step": dt / args.steps * 1e6,
                   "algorithmic_GBs": frames * bpf / dt / 1e9, "frac_of_8TBs": frames * bpf / dt / 8e12}))
