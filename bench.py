@@ -66,7 +66,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense f16 / bf16 MFMA p
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 PRODUCTS = 4.0                    # f16 MFMA products per f32-equivalent product in the default mode
 B_PER_GPU, SECONDS, N_MELS = 256, 10.0, 64
-PROFILE_TAGS = ("r04", "r03")     # committed rocprofv3 summaries quoted on the line (profiles/<tag>_*), newest first
+PROFILE_TAGS = ("r05", "r04", "r03")     # committed rocprofv3 summaries quoted on the line (profiles/<tag>_*), newest first
 
 
 def log(msg):
