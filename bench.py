@@ -23,7 +23,7 @@ measured at a clock the job does not keep (`settle` on the line; `sustained` = t
 
 Extra objects on the JSON line:
   roofline     -- the kernel with the largest share of a step's kernel time (rocprofv3 --kernel-trace --stats of the step submitted
-                  alone: profiles/r04_bench_sequential_kernel_stats.csv), lstm_rec16h_kernel: ALGORITHMIC f32-equivalent FLOP of one
+                  alone: profiles/r05_bench_sequential_kernel_stats.csv), lstm_rec16h_kernel: ALGORITHMIC f32-equivalent FLOP of one
                   launch (2 x 4H x H per frame, direction and layer) / its launch duration MEASURED WITH THE GPU TO
                   ITSELF (HIP events around that launch on its own stream: the number rocprofv3 reports for it), against the
                   f32-accurate ceiling of the f16 matrix pipe (2500 TFLOP/s dense / 4 MFMA products per f32-equivalent product);
@@ -511,7 +511,7 @@ def alone_on_gpu(rt, dev, pcm, tile):
     """Launch durations with the GPU to itself: the step is submitted ALONE on one stream, in the recurrent form of the headline
     (`tile`), and the library brackets every layer's projection and recurrence with HIP events on that stream
     (uvad_get_layer_timing).  These are the durations rocprofv3 --kernel-trace reports for the same kernels in a sequential run
-    (profiles/r04_bench_sequential_kernel_stats.csv).  Median of 5 steps."""
+    (profiles/r05_bench_sequential_kernel_stats.csv).  Median of 5 steps."""
     rt.set_recurrent_tile(tile)   # (the pipeline's contexts already run this form; a no-op for them)
     for _ in range(2):
         rt.forward(pcm, want_probs=False)

@@ -8,7 +8,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 3 --warmup 1 --settle 0 --no-cpu-baseline --no-sequential --no-sincnet --in-flight 1 $*"
+BENCH="python3 $REPO/bench.py --steps 3 --warmup 1 --settle 0 --no-cpu-baseline --no-sequential --no-sincnet --no-reference-shape --in-flight 1 $*"
 run_pass() {   # name, counters...
     local name=$1; shift
     echo "[profile] pass $name: $*"
@@ -18,9 +18,9 @@ run_pass() {   # name, counters...
     if [ $rc -ne 0 ]; then echo "[profile] pass $name failed with rc $rc (unknown counter?): see $OUT/$name.log; continuing"; tail -3 "$OUT/$name.log"; fi
 }
 echo "[profile] kernel stats"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sincnet "$@" > "$OUT/stats.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-sincnet --no-reference-shape "$@" > "$OUT/stats.log" 2>&1
 echo "[profile] kernel stats of the step submitted alone (throughput recurrence)"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/seqstats" -- python3 $REPO/bench.py --steps 5 --warmup 2 --settle 0 --in-flight 1 --rec-tile 16 --no-cpu-baseline --no-sincnet --no-sequential > "$OUT/seqstats.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/seqstats" -- python3 $REPO/bench.py --steps 5 --warmup 2 --settle 0 --in-flight 1 --rec-tile 16 --no-cpu-baseline --no-sincnet --no-sequential --no-reference-shape > "$OUT/seqstats.log" 2>&1
 run_pass fetch FETCH_SIZE
 run_pass write WRITE_SIZE
 run_pass p1 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES
