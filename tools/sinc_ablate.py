@@ -14,6 +14,7 @@ VARIANTS = {
     "nostage": ["stage"],
     "noprefetch": ["prefetch"],
     "mfma_only": ["epi", "stage", "prefetch"],
+    "stamps": ["stamps"],      # s_memtime around the parts of a tile; block 0 / wave 0 prints the sums (cycles) at the end of each launch
 }
 
 
@@ -25,6 +26,17 @@ def patch(src, what):
                          "                for (int i = 0; i < 4; ++i) z += hi[rb][i] + lo[rb][i];\n"
                          "            m[0] = m[1] = m[2] = m[3] = z;\n            if (z == 123456.75f) out_tile[n] = z;\n            const int sig_q = 0;\n") + src[j:]
         src = src.replace("            float s = sl + __shfl_xor(sl, 16);", "            if (cnt != -12345) { if (sl == 123456.75f) a.partials[n] = sl; return; }\n            float s = sl + __shfl_xor(sl, 16);")
+    if "stamps" in what:
+        src = src.replace("    int cur_b = -1;\n    prefetch(g_begin);", "    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};\n    int st_tiles = 0;\n#define STAMP() __builtin_amdgcn_s_memtime()\n    int cur_b = -1;\n    prefetch(g_begin);")
+        src = src.replace("        __syncthreads();   // the previous tile's fragment reads are complete\n", "        const unsigned long long s0 = STAMP();\n        __syncthreads();   // the previous tile's fragment reads are complete\n        const unsigned long long s1 = STAMP();\n")
+        src = src.replace("        stage(b, tile);\n        __syncthreads();\n        if (gi + 1 < g_end) prefetch(gi + 1);\n",
+                          "        stage(b, tile);\n        const unsigned long long s2 = STAMP();\n        __syncthreads();\n        const unsigned long long s3 = STAMP();\n        if (gi + 1 < g_end) prefetch(gi + 1);\n        const unsigned long long s4 = STAMP();\n        unsigned long long mf = 0, ep = 0;\n")
+        src = src.replace("            // lane (n, q): positions 12 sigma(g, q) + 4 rb + i, i = 0 .. 3.  u = hi + lo * 2^-11;", "            const unsigned long long m1 = STAMP();\n            // lane (n, q): positions 12 sigma(g, q) + 4 rb + i, i = 0 .. 3.  u = hi + lo * 2^-11;")
+        src = src.replace("            f32x4 hi[3], lo[3];\n            f16x8 fh[2][3], fl[2][3];", "            const unsigned long long m0 = STAMP();\n            f32x4 hi[3], lo[3];\n            f16x8 fh[2][3], fl[2][3];")
+        src = src.replace("            return sig_q;\n        };", "            const unsigned long long m2 = STAMP();\n            mf += m1 - m0; ep += m2 - m1;\n            return sig_q;\n        };")
+        # end of tile: after the last put_stats -> accumulate
+        src = src.replace("            }, wave, 4);\n        }\n    }\n}", "            }, wave, 4);\n        }\n        UVAD_TILE_END\n    }\n    UVAD_KERNEL_END\n}")
+        src = src.replace("#include \"uvad_internal.h\"", "#include \"uvad_internal.h\"\n#include <cstdio>\n#define UVAD_TILE_END { const unsigned long long s5 = STAMP(); st_acc[0] += s1 - s0; st_acc[1] += s2 - s1; st_acc[2] += s3 - s2; st_acc[3] += s4 - s3; st_acc[4] += mf; st_acc[5] += ep; st_acc[6] += s5 - s4 - mf - ep; st_acc[7] += s5 - s0; ++st_tiles; }\n#define UVAD_KERNEL_END if (blockIdx.x == 0 && threadIdx.x == 0) printf(\"STAMPS stage %d tiles %d barrier1 %llu stage %llu barrier2 %llu prefetch %llu mfma %llu epilogue %llu stats %llu total %llu\\n\", ST, st_tiles, st_acc[0] / st_tiles, st_acc[1] / st_tiles, st_acc[2] / st_tiles, st_acc[3] / st_tiles, st_acc[4] / st_tiles, st_acc[5] / st_tiles, st_acc[6] / st_tiles, st_acc[7] / st_tiles);")
     if "stage" in what:
         src = src.replace("        stage(b, tile);\n", "        if (a.Lpool == -7) stage(b, tile);\n")
     if "prefetch" in what:
@@ -55,6 +67,8 @@ def run():
         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
         d = json.loads(line[-1]) if line else {"error": p.stderr[-400:]}
         print(json.dumps({"variant": name, "sincnet_ms": d.get("sincnet_ms"), "stage_ms": d.get("stage_ms")}), flush=True)
+        for l in sorted(set(l for l in p.stdout.splitlines() if l.startswith("STAMPS"))):
+            print(l, flush=True)
 
 
 if __name__ == "__main__":

@@ -127,9 +127,32 @@ __global__ __launch_bounds__(256, 1) void sinc_conv_f16p_kernel(SincF16Args a) {
 
     // ---- the window of a tile travels global -> registers (prefetch: issued BEFORE the previous tile's MFMAs, so HBM / L2 latency hides
     //      under them) -> LDS (stage: norm, leaky_relu and the f16 split, after them).  Stage 1: chunks of 8 samples, thread t takes chunk t
-    //      and, for t < 16, chunk 256 + t; stages 2 / 3: 16-byte units u = t + 256 i of the contiguous [row][channel] window.
-    constexpr int NPRE = ST == 1 ? 4 : (Stage<ST == 1 ? 2 : ST>::ROWS * (Stage<ST == 1 ? 2 : ST>::IN_CST / 4) + 255) / 256;
+    //      and, for t < 16, chunk 256 + t.  Stages 2 / 3: 16-byte units of the contiguous [row][channel] window, RPP whole rows per pass: thread
+    //      t < THR owns the SAME four channels c4 = t mod U in every pass (its (scale, shift) are read from the LDS table once per tile, not once
+    //      per unit: 32 dependent LDS reads and their latency per tile were the largest part of a 5 300-cycle staging) and rows t / U + RPP i.
+    constexpr int SIN_CST = Stage<ST == 1 ? 2 : ST>::IN_CST, SU = SIN_CST / 4, RPP = 256 / SU, THR = RPP * SU, SROWS = Stage<ST == 1 ? 2 : ST>::ROWS;
+    constexpr int NPRE = ST == 1 ? 4 : (SROWS + RPP - 1) / RPP;
     float4 pre[NPRE];
+    // Stages 2 / 3: where the window of tile gi starts and how many of its rows exist; pf_load(i) fetches this thread's unit of pass i.  Every
+    // load is UNCONDITIONAL (a thread past THR, a row past the window or past the utterance re-reads unit 0: stage() ignores it / stages zeros),
+    // so a load is one address select and one instruction, and the loads of the NEXT tile can be issued one at a time between the k-steps of the
+    // current one (pf_slot): issued as one burst in front of the MFMAs they held the wave for 2 100 - 2 600 cycles per tile -- the CU's vector
+    // memory path takes 17 x 4 KiB from four waves at once -- with the matrix pipe idle.
+    const float *pf_src = a.in;
+    int pf_rows = 0;
+    auto pf_setup = [&](long long gi) __attribute__((always_inline)) {
+        const int b = (int)(gi / a.ntiles), tile = (int)(gi - (long long)b * a.ntiles);
+        const long long x0s = (long long)tile * TILE_POS, left = (long long)a.Lin - x0s;
+        pf_src = a.in + ((size_t)b * a.Lin + x0s) * (ST == 1 ? 1 : SIN_CST);
+        pf_rows = left < SROWS ? (int)left : SROWS;
+    };
+    auto pf_load = [&](int i) __attribute__((always_inline)) {
+        const int r0 = tid / SU;
+        const bool ok = tid < THR && r0 + RPP * i < pf_rows;
+        pre[i] = *reinterpret_cast<const float4 *>(pf_src + (size_t)(ok ? (tid + THR * i) * 4 : 0));
+    };
+    // the k-step slot (group * (KS - 1) + ks - 1, ks = 1 .. KS - 1) in which unit i of the next tile is fetched: spread evenly over the tile
+    auto pf_slot = [](int i) { return (i * NGROUP * (KS - 1)) / NPRE; };
     auto prefetch = [&](long long gi) __attribute__((always_inline)) {
         const int b = (int)(gi / a.ntiles), tile = (int)(gi - (long long)b * a.ntiles);
         if constexpr (ST == 1) {
@@ -157,16 +180,9 @@ __global__ __launch_bounds__(256, 1) void sinc_conv_f16p_kernel(SincF16Args a) {
                 pre[2 * r + 1] = hi4;
             }
         } else {
-            constexpr int U = S::IN_CST / 4;
-            const long long x0s = (long long)tile * TILE_POS;
-            const float *src = a.in + ((size_t)b * a.Lin + x0s) * S::IN_CST;
+            pf_setup(gi);
 #pragma unroll
-            for (int i = 0; i < NPRE; ++i) {
-                const int u = tid + 256 * i, row = u / U;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (u < S::ROWS * U && x0s + row < a.Lin) v = *reinterpret_cast<const float4 *>(src + (size_t)u * 4);   // (the window is one contiguous run)
-                pre[i] = v;
-            }
+            for (int i = 0; i < NPRE; ++i) pf_load(i);
         }
     };
     auto stage = [&](int b, int tile) __attribute__((always_inline)) {
@@ -204,13 +220,16 @@ __global__ __launch_bounds__(256, 1) void sinc_conv_f16p_kernel(SincF16Args a) {
             }
         } else {
             const float *nrm = reinterpret_cast<const float *>(smem + 2 * S::LO_OFF);
-            constexpr int U = S::IN_CST / 4;
-            int row = tid / U, c4 = tid - row * U;            // unit u = tid + 256 i walks (row, c4) incrementally
+            const int r0 = tid / SU, c4 = tid - r0 * SU;
+            const float4 sc = *reinterpret_cast<const float4 *>(nrm + 4 * c4), sh = *reinterpret_cast<const float4 *>(nrm + 80 + 4 * c4);   // (c4 < 20: inside the table for every thread)
+            unsigned char *d = smem + r0 * S::ROWB + 8 * c4;
+            const long long left = (long long)a.Lin - (long long)tile * TILE_POS;
+            const int rows = left < SROWS ? (int)left : SROWS;                   // rows of this window that exist (the others: the unit-0 re-read, staged as zero)
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) {
-                if (i + 1 < NPRE || tid + 256 * i < S::ROWS * U) {
-                    const float4 v = pre[i];
-                    const float4 sc = *reinterpret_cast<const float4 *>(nrm + 4 * c4), sh = *reinterpret_cast<const float4 *>(nrm + 80 + 4 * c4);
+                if (tid < THR && (i + 1 < NPRE || r0 + RPP * i < SROWS)) {
+                    float4 v = pre[i];
+                    if (rows < SROWS && r0 + RPP * i >= rows) v = make_float4(0.f, 0.f, 0.f, 0.f);   // (the utterance's last tile only)
                     const float e[4] = {__builtin_fmaf(v.x, sc.x, sh.x), __builtin_fmaf(v.y, sc.y, sh.y), __builtin_fmaf(v.z, sc.z, sh.z), __builtin_fmaf(v.w, sc.w, sh.w)};
                     _Float16 h[4], l[4];
 #pragma unroll
@@ -221,12 +240,9 @@ __global__ __launch_bounds__(256, 1) void sinc_conv_f16p_kernel(SincF16Args a) {
                     uint2 ph, pl;
                     __builtin_memcpy(&ph, h, 8);
                     __builtin_memcpy(&pl, l, 8);
-                    unsigned char *d = smem + row * S::ROWB + 8 * c4;
-                    *reinterpret_cast<uint2 *>(d) = ph;
-                    *reinterpret_cast<uint2 *>(d + S::LO_OFF) = pl;
+                    *reinterpret_cast<uint2 *>(d + i * (RPP * S::ROWB)) = ph;
+                    *reinterpret_cast<uint2 *>(d + i * (RPP * S::ROWB) + S::LO_OFF) = pl;
                 }
-                row += 256 / U; c4 += 256 % U;
-                if (256 % U != 0 && c4 >= U) { c4 -= U; ++row; }
             }
         }
     };
@@ -250,7 +266,11 @@ __global__ __launch_bounds__(256, 1) void sinc_conv_f16p_kernel(SincF16Args a) {
         }
         stage(b, tile);
         __syncthreads();
-        if (gi + 1 < g_end) prefetch(gi + 1);
+        if constexpr (ST == 1) {
+            if (gi + 1 < g_end) prefetch(gi + 1);
+        } else {
+            pf_setup(gi + 1 < g_end ? gi + 1 : gi);   // (the range's last tile re-reads its own window: no branch in the MFMA stream)
+        }
 
         // ---------------- one group (48 positions) against one channel tile: 3 row blocks x KS k-steps x 4 products, then the epilogue.
         // The A fragments of k-step ks + 1 are read while the twelve MFMAs of k-step ks run (two fragment sets, the order pinned with
@@ -312,6 +332,13 @@ __global__ __launch_bounds__(256, 1) void sinc_conv_f16p_kernel(SincF16Args a) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ST != 1) {   // this k-step's share of the next tile's window (own channel tiles only: ctile < NGROUP)
+                    if (ctile < NGROUP && ks >= 1) {
+#pragma unroll
+                        for (int i = 0; i < NPRE; ++i)
+                            if (pf_slot(i) == g * (KS - 1) + ks - 1) pf_load(i);
+                    }
+                }
             }
             // lane (n, q): positions 12 sigma(g, q) + 4 rb + i, i = 0 .. 3.  u = hi + lo * 2^-11; the stage's value is u * 2^-S + bias (stage 1: |u| * 2^-S,
             // the sinc bank has no bias), a non-decreasing map of u (of |u|), so MaxPool1d(3) is taken on u and the affine map applied to the
