@@ -11,6 +11,10 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--mode", default="f16p", choices=["f16p", "f16p_stream", "f32", "f16p3"])
 ap.add_argument("--tile", type=int, default=0, help="recurrent form: 0 = by estimated time, 4, 16")
+ap.add_argument("--seconds", type=float, default=10.0)
+ap.add_argument("--mels", type=int, default=64)
+ap.add_argument("--window", default="hamming")
+ap.add_argument("--chunks", type=int, default=0, help="time chunks: 0 = automatic, 1 = off")
 args = ap.parse_args()
 import uvad_amd
 from uvad_amd import _lib
@@ -18,12 +22,13 @@ if args.lib:
     _lib.LIB_PATH = os.path.abspath(args.lib)
 from uvad_amd.synth import seed_weights, synth_pcm_device
 dev = torch.device("cuda:0")
-m = uvad_amd.PyanNet2(encoding_dim=64); m.build(); seed_weights(m, 1234, 4.0)
-m.attach_fbank(uvad_amd.FbankConfig(num_filters=64, window_type="hamming")); m = m.to(dev).eval()
+m = uvad_amd.PyanNet2(encoding_dim=args.mels); m.build(); seed_weights(m, 1234, 4.0)
+m.attach_fbank(uvad_amd.FbankConfig(num_filters=args.mels, window_type=args.window)); m = m.to(dev).eval()
 rt = m.runtime(dev)
 rt.set_gemm_mode(args.mode)
 rt.set_recurrent_tile(args.tile)
-pcm = synth_pcm_device(args.batch, 160000, seed=42, device=dev)
+rt.set_time_chunks(args.chunks)
+pcm = synth_pcm_device(args.batch, int(args.seconds * 16000), seed=42, device=dev)
 for _ in range(3):
     rt.forward(pcm, want_probs=False)
 torch.cuda.synchronize()
