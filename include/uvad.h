@@ -98,6 +98,11 @@ int uvad_set_weight(uvad_ctx *, const char *torch_key, const float *host, const 
  * upload and replaces it -- so every hipGraph captured from this context earlier (it bakes the old device pointers of the
  * weights into its kernel nodes) is INVALID afterwards and must be captured again. */
 int uvad_finalize(uvad_ctx *);
+/* Contexts of one process that are finalized with identical tensors, model / SincNet configuration and device SHARE the packed weights on the
+ * device (read-only there; repacked and uploaded once: a pipeline of twelve contexts pays the ~45 ms of host-side packing once, not twelve times).
+ * Transparent: a context that swaps a weight and finalizes again gets a block of its own, the others keep theirs; a block is freed with its last
+ * context.  Returns how many contexts currently use this context's block (1 = not shared; 0 before uvad_finalize; negative on error). */
+int uvad_weights_shared_by(const uvad_ctx *);
 
 /* T for S samples (lhotse framing; data/test_data.py:23 pins T = S/160 for 5 s cuts). */
 int64_t uvad_num_frames(const uvad_ctx *, int64_t S);

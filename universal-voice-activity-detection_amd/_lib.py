@@ -76,6 +76,7 @@ SIGNATURES = {
     "uvad_get_recurrent_tile": (C.c_int, [C.c_void_p]),
     "uvad_get_p2_on_fp8": (C.c_int, [C.c_void_p]),
     "uvad_get_sincnet_form": (C.c_int, [C.c_void_p]),
+    "uvad_weights_shared_by": (C.c_int, [C.c_void_p]),
     "uvad_set_time_chunks": (C.c_int, [C.c_void_p, C.c_int]),
     "uvad_get_time_chunks": (C.c_int, [C.c_void_p]),
     "uvad_recurrent_tile_for": (C.c_int, [C.c_void_p, C.c_int]),

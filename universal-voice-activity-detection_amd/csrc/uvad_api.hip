@@ -12,6 +12,8 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <set>
 #include <tuple>
 #include <string>
@@ -38,6 +40,36 @@ struct LayerDev {
     float *w_hh16_scale = nullptr;          // [dirs] 2^-S
     bool w_hh16_ok = false;
     int in = 0;
+};
+
+// Everything uvad_finalize produces from the host tensors: the device buffers (owned here, freed with the last owner) and the values derived
+// while packing.  Contexts that are finalized with IDENTICAL host tensors, model / SincNet configuration and device share one of these through a
+// process-wide cache (find_or_insert_packed): the twelve slots of a ForwardPipeline, or the three of predict_vad, repack and upload the 6 MB of
+// weights once instead of once per context (host-side packing is ~45 ms per context: it was 0.18 of the 0.26 s predict_vad spends on a one-hour
+// recording).  Read-only on the device, so sharing needs no synchronisation; a weight hot-swap gives the swapping context a block of its own.
+struct PackedWeights {
+    int device = 0;
+    std::vector<void *> allocs;
+    std::vector<LayerDev> layers;
+    bool f16_ok = true;
+    std::vector<float *> lin_w, lin_b, lin_w_img;
+    std::vector<unsigned short *> lin_w_split16;
+    std::vector<float> lin_w_scale;
+    float *cls_w = nullptr, *cls_b = nullptr;
+    bool sinc_ready = false, sinc_f16 = false;
+    float *sn_wav_g = nullptr, *sn_wav_b = nullptr;
+    float *sn_wt[3] = {nullptr, nullptr, nullptr}, *sn_bias[3] = {nullptr, nullptr, nullptr}, *sn_g[3] = {nullptr, nullptr, nullptr}, *sn_b[3] = {nullptr, nullptr, nullptr};
+    unsigned short *sn_wfrag[3] = {nullptr, nullptr, nullptr};
+    float sn_wscale[3] = {1.f, 1.f, 1.f}, *sn_bias16[3] = {nullptr, nullptr, nullptr};
+    float sn_in_gmax[3] = {0.f, 0.f, 0.f}, sn_in_bmax[3] = {0.f, 0.f, 0.f};
+    ~PackedWeights() {
+        if (allocs.empty()) return;
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(device);
+        for (void *p : allocs) (void)hipFree(p);
+        if (cur >= 0) (void)hipSetDevice(cur);
+    }
 };
 
 // Row tiles of the tile-major activation matrices (row = (tile * T + t) * 4 + j, 128-row tiles) by the time chunk that needs them first:
@@ -90,7 +122,8 @@ struct uvad_ctx {
     float sn_wscale[3] = {1.f, 1.f, 1.f}, *sn_bias16[3] = {nullptr, nullptr, nullptr};
     float sn_in_gmax[3] = {0.f, 0.f, 0.f}, sn_in_bmax[3] = {0.f, 0.f, 0.f};
     std::vector<void *> allocs;          // feature tables, twiddles: live as long as the context
-    std::vector<void *> weight_allocs;   // everything uvad_finalize uploads: replaced by the next uvad_finalize
+    std::vector<void *> weight_allocs;   // what the uvad_finalize in progress has uploaded so far (moved into `packed` when it succeeds)
+    std::shared_ptr<PackedWeights> packed;   // the finalized weights this context uses (possibly shared with other contexts: PackedWeights)
     // timing
     bool timing = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -411,13 +444,14 @@ int uvad_set_weight(uvad_ctx *c, const char *torch_key, const float *host, const
 extern "C++" {
 namespace {
 void free_weights(uvad_ctx *c) {
-    for (void *p : c->weight_allocs) (void)hipFree(p);
+    for (void *p : c->weight_allocs) (void)hipFree(p);   // (leftovers of a uvad_finalize that failed half-way)
     c->weight_allocs.clear();
+    c->packed.reset();                                   // the shared block goes with its last owner
     for (auto &ev : c->layer_ev)
         if (ev) (void)hipEventDestroy(ev);
     c->layer_ev.clear();
     c->layers.clear();
-    c->lin_w.clear(); c->lin_b.clear(); c->lin_w_split16.clear(); c->lin_w_scale.clear();
+    c->lin_w.clear(); c->lin_b.clear(); c->lin_w_split16.clear(); c->lin_w_scale.clear(); c->lin_w_img.clear();
     c->cls_w = c->cls_b = nullptr;
     c->sn_wav_g = c->sn_wav_b = nullptr;
     for (int i = 0; i < 3; ++i) {
@@ -430,16 +464,105 @@ void free_weights(uvad_ctx *c) {
 }  // namespace
 }  // extern "C++"
 
+extern "C++" {
+namespace {
+// 128-bit digest of everything the packed weights depend on: device, model / SincNet configuration, every host tensor (name, shape, bytes)
+struct WeightKey {
+    unsigned long long h[2];
+    bool operator<(const WeightKey &o) const { return h[0] != o.h[0] ? h[0] < o.h[0] : h[1] < o.h[1]; }
+};
+inline void mix(WeightKey &k, const void *p, size_t n) {
+    const unsigned char *b = reinterpret_cast<const unsigned char *>(p);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        unsigned long long w;
+        memcpy(&w, b + i, 8);
+        k.h[0] = (k.h[0] ^ w) * 0x9E3779B97F4A7C15ull; k.h[0] ^= k.h[0] >> 29;
+        k.h[1] = (k.h[1] + w) * 0xC2B2AE3D27D4EB4Full; k.h[1] ^= k.h[1] >> 31;
+    }
+    for (; i < n; ++i) {
+        k.h[0] = (k.h[0] ^ b[i]) * 0x100000001B3ull;
+        k.h[1] = (k.h[1] + b[i]) * 0x9E3779B97F4A7C15ull; k.h[1] ^= k.h[1] >> 27;
+    }
+}
+WeightKey weight_key(const uvad_ctx *c) {
+    WeightKey k{{0xcbf29ce484222325ull, 0x84222325cbf29ce4ull}};
+    mix(k, &c->device, sizeof c->device);
+    mix(k, &c->mc, sizeof c->mc);
+    const int hs = c->has_sinc ? 1 : 0;
+    mix(k, &hs, sizeof hs);
+    if (c->has_sinc) mix(k, &c->sc, sizeof c->sc);
+    for (const auto &kv : c->host_w) {   // std::map: key order
+        mix(k, kv.first.data(), kv.first.size());
+        const size_t nd = kv.second.shape.size();
+        mix(k, &nd, sizeof nd);
+        mix(k, kv.second.shape.data(), nd * sizeof(int64_t));
+        mix(k, kv.second.data.data(), kv.second.data.size() * sizeof(float));
+    }
+    return k;
+}
+std::mutex packed_mu;
+std::map<WeightKey, std::weak_ptr<PackedWeights>> packed_cache;
+
+// the context's view of a block: plain copies of the pointers and flags (the launch code reads them from the context as before)
+void adopt_packed(uvad_ctx *c, const std::shared_ptr<PackedWeights> &pw) {
+    c->packed = pw;
+    c->layers = pw->layers; c->f16_ok = pw->f16_ok;
+    c->lin_w = pw->lin_w; c->lin_b = pw->lin_b; c->lin_w_img = pw->lin_w_img; c->lin_w_split16 = pw->lin_w_split16; c->lin_w_scale = pw->lin_w_scale;
+    c->cls_w = pw->cls_w; c->cls_b = pw->cls_b;
+    c->sinc_ready = pw->sinc_ready; c->sinc_f16 = pw->sinc_f16;
+    c->sn_wav_g = pw->sn_wav_g; c->sn_wav_b = pw->sn_wav_b;
+    for (int i = 0; i < 3; ++i) {
+        c->sn_wt[i] = pw->sn_wt[i]; c->sn_bias[i] = pw->sn_bias[i]; c->sn_g[i] = pw->sn_g[i]; c->sn_b[i] = pw->sn_b[i];
+        c->sn_wfrag[i] = pw->sn_wfrag[i]; c->sn_wscale[i] = pw->sn_wscale[i]; c->sn_bias16[i] = pw->sn_bias16[i];
+        c->sn_in_gmax[i] = pw->sn_in_gmax[i]; c->sn_in_bmax[i] = pw->sn_in_bmax[i];
+    }
+}
+std::shared_ptr<PackedWeights> snapshot_packed(uvad_ctx *c) {
+    auto pw = std::make_shared<PackedWeights>();
+    pw->device = c->device;
+    pw->allocs.swap(c->weight_allocs);
+    pw->layers = c->layers; pw->f16_ok = c->f16_ok;
+    pw->lin_w = c->lin_w; pw->lin_b = c->lin_b; pw->lin_w_img = c->lin_w_img; pw->lin_w_split16 = c->lin_w_split16; pw->lin_w_scale = c->lin_w_scale;
+    pw->cls_w = c->cls_w; pw->cls_b = c->cls_b;
+    pw->sinc_ready = c->sinc_ready; pw->sinc_f16 = c->sinc_f16;
+    pw->sn_wav_g = c->sn_wav_g; pw->sn_wav_b = c->sn_wav_b;
+    for (int i = 0; i < 3; ++i) {
+        pw->sn_wt[i] = c->sn_wt[i]; pw->sn_bias[i] = c->sn_bias[i]; pw->sn_g[i] = c->sn_g[i]; pw->sn_b[i] = c->sn_b[i];
+        pw->sn_wfrag[i] = c->sn_wfrag[i]; pw->sn_wscale[i] = c->sn_wscale[i]; pw->sn_bias16[i] = c->sn_bias16[i];
+        pw->sn_in_gmax[i] = c->sn_in_gmax[i]; pw->sn_in_bmax[i] = c->sn_in_bmax[i];
+    }
+    return pw;
+}
+}  // namespace
+}  // extern "C++"
+
 int uvad_finalize(uvad_ctx *c) {
     if (!c) return UVAD_E_ARG;
     if (!c->has_model) return fail(c, UVAD_E_STATE, "no model configuration");
     HIPCHK(c, hipSetDevice(c->device));
     // Idempotent: a second call (e.g. after swapping weights with uvad_set_weight) replaces the previous upload.
     // Kernels of earlier calls may still be reading the old buffers.
-    if (!c->weight_allocs.empty()) HIPCHK(c, hipDeviceSynchronize());
+    if (c->packed || !c->weight_allocs.empty()) HIPCHK(c, hipDeviceSynchronize());
     free_weights(c);
     const uvad_model_cfg &m = c->mc;
     const int H = m.hidden, D = m.bidirectional ? 2 : 1;
+    // another context of this process already holds these very weights in kernel layouts on this device: share them
+    const WeightKey wkey = weight_key(c);
+    {
+        std::lock_guard<std::mutex> lk(packed_mu);
+        auto it = packed_cache.find(wkey);
+        if (it != packed_cache.end()) {
+            if (std::shared_ptr<PackedWeights> pw = it->second.lock()) {
+                adopt_packed(c, pw);
+                c->layer_ev.assign((size_t)2 * m.num_layers + 2, nullptr);
+                for (auto &ev : c->layer_ev) HIPCHK(c, hipEventCreate(&ev));
+                c->finalized = true;
+                return UVAD_OK;
+            }
+            packed_cache.erase(it);
+        }
+    }
     auto get = [&](const std::string &k) -> const HostTensor * {
         auto it = c->host_w.find(k);
         return it == c->host_w.end() ? nullptr : &it->second;
@@ -614,6 +737,14 @@ int uvad_finalize(uvad_ctx *c) {
             if ((r = dev_upload(c, bias.data(), bias.size(), &c->sn_bias16[i], true))) return r;
         }
         c->sinc_ready = true;
+    }
+    {   // the uploads become a block other contexts with the same weights can share
+        std::shared_ptr<PackedWeights> pw = snapshot_packed(c);
+        c->packed = pw;
+        std::lock_guard<std::mutex> lk(packed_mu);
+        for (auto it = packed_cache.begin(); it != packed_cache.end();)   // (entries whose block is gone: a process that cycles through weight sets)
+            it = it->second.expired() ? packed_cache.erase(it) : std::next(it);
+        packed_cache[wkey] = pw;
     }
     c->finalized = true;
     return UVAD_OK;
@@ -1450,6 +1581,11 @@ int uvad_set_recurrent_tile(uvad_ctx *c, int sequences) {
 }
 
 int uvad_get_recurrent_tile(const uvad_ctx *c) { return c ? c->rec_tile_used : UVAD_E_ARG; }
+int uvad_weights_shared_by(const uvad_ctx *c) {
+    if (!c) return UVAD_E_ARG;
+    return c->packed ? (int)c->packed.use_count() : 0;
+}
+
 int uvad_get_sincnet_form(const uvad_ctx *c) {
     if (!c) return UVAD_E_ARG;
     return c->sinc_f16_used ? 1 : 0;
@@ -1526,7 +1662,7 @@ const char *uvad_last_error(const uvad_ctx *c) { return c ? c->err.c_str() : "nu
 
 void uvad_destroy(uvad_ctx *c) {
     if (!c) return;
-    if (!c->allocs.empty() || !c->weight_allocs.empty() || c->ev[0]) (void)hipSetDevice(c->device);
+    if (!c->allocs.empty() || !c->weight_allocs.empty() || c->packed || c->ev[0]) (void)hipSetDevice(c->device);
     free_weights(c);
     for (void *p : c->allocs) (void)hipFree(p);
     for (auto &ev : c->ev)

@@ -329,6 +329,11 @@ class VadRuntime:
         """True if the 16-sequence recurrence runs its P2 x h product on the 8-bit matrix pipe (every P2 element exactly bf8: include/uvad.h)."""
         return bool(self.lib.uvad_get_p2_on_fp8(self.ctx))
 
+    def weights_shared_by(self) -> int:
+        """How many contexts of this process use this context's packed weights on the device (include/uvad.h: contexts finalized with
+        identical tensors share them; 1 = not shared)."""
+        return int(self.lib.uvad_weights_shared_by(self.ctx))
+
     def sincnet_form(self) -> str:
         """What the most recent sincnet() / forward_wav() ran: "f16p" (the split-f16 stages of sincnet_f16p.hip) or "f32" (sincnet.hip)."""
         return "f16p" if int(self.lib.uvad_get_sincnet_form(self.ctx)) == 1 else "f32"
