@@ -22,8 +22,11 @@ if [ "$MODE" = "pmc" ]; then
     run_pass p2 SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES
     run_pass p3 SQ_INSTS_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES
     run_pass p4 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_UNALIGNED_STALL SQ_WAVE_CYCLES
+    run_pass fetch FETCH_SIZE
+    run_pass write WRITE_SIZE
     cd "$REPO"
     python3 tools/pmc_summary.py counters "$OUT/p1" "$OUT/p2" "$OUT/p3" "$OUT/p4" > "$OUT/counters.json"
-    rm -rf "$OUT/p1" "$OUT/p2" "$OUT/p3" "$OUT/p4"
+    python3 tools/pmc_summary.py traffic "$OUT/fetch" "$OUT/write" > "$OUT/hbm_traffic.json"
+    rm -rf "$OUT/p1" "$OUT/p2" "$OUT/p3" "$OUT/p4" "$OUT/fetch" "$OUT/write"
 fi
 echo "[profile] done: $OUT"
