@@ -196,6 +196,36 @@ def test_sincnet_split_f16_form_is_refused_outside_the_f16_range_and_the_referen
     assert rt.sincnet_form() == "f16p" and np.abs(short.cpu().numpy() - front(wav[:, :16000].unsqueeze(1)).transpose(1, 2).numpy()).max() < FEAT_TOL
 
 
+def test_forward_wav_replayed_from_a_hipgraph_equals_the_eager_call():
+    """uvad_forward_wav enqueues only (no allocation, no synchronisation, no host read-back): the whole PyanNet step -- waveform statistics,
+    the three split-f16 conv stages with their norm finalisations, the output pass, the classifier -- is capturable into a hipGraph and the replay
+    gives the eager call's bits, for both forms of the SincNet stages."""
+    from oracle import torch_ref as tr
+    _, _, m = _pair(seed=17)
+    dev = torch.device("cuda:0")
+    rt = m.runtime(dev)
+    wav = torch.from_numpy(tr.synth_pcm(6, 40000, seed=21)).to(dev)
+    for mode in ("f16p", "f32"):
+        rt.set_gemm_mode(mode)
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(side):
+            eager, eager_p = (t.clone() for t in rt.forward_wav(wav))            # (also sizes the workspace outside the capture)
+            form = rt.sincnet_form()
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                cap, cap_p = rt.forward_wav(wav)
+        assert form == mode
+        cap.zero_(); cap_p.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(cap, eager) and torch.equal(cap_p, eager_p), mode
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(cap, eager)
+    rt.set_gemm_mode("f16p")
+
+
 def test_sincnet_batch_invariance_and_determinism():
     """An utterance's features do not depend on its batch neighbours or on scheduling (tile-ordered statistics)."""
     from oracle import torch_ref as tr
