@@ -64,38 +64,31 @@ __device__ __forceinline__ float lstm_cell(const f32x4 g, float &c) {
     return og * tanh_f(c);
 }
 
-// Two cell updates at once for the 16-sequence kernel, which is bound by vector-instruction issue (four cells per lane and
-// step): the arithmetic runs as packed f32 pairs (v_pk_mul/add/fma_f32: two cells per instruction) and two of the five
+// The cell update of the 16-sequence kernel, which is bound by vector-instruction issue (four cells per lane and step): two of the five
 // reciprocals per cell disappear by dividing once per PRODUCT,
 //     sigmoid(i) * tanh(g) = sign(g) (1 - eg) / ((1 + ei)(1 + eg)),   sigmoid(o) * tanh(c) = sign(c) (1 - ec) / ((1 + eo)(1 + ec))
 // with e* = exp2 of the clamped negated pre-activation as in sigmoid_f / tanh_f (the denominators stay below 2^127: ei <= 2^125,
-// eg <= 1).  Each quotient is v_rcp_f32 + one Newton step on the quotient, i.e. correctly rounded up to 2^-46 like tanh_f's.
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-__device__ __forceinline__ f32x2 exp2_2(f32x2 x) { return f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])}; }
-__device__ __forceinline__ f32x2 quot_2(f32x2 n, f32x2 d) {   // n / d, d in [1, 2^127)
-    const f32x2 r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    const f32x2 q = n * r;
-    return __builtin_elementwise_fma(__builtin_elementwise_fma(-d, q, n), r, q);
+// eg <= 1).  Each quotient is v_rcp_f32 + one Newton step on the quotient, i.e. correctly rounded up to 2^-46 like tanh_f's (without the
+// Newton step the launch is SLOWER -- its fmas fill the transcendentals' issue slots -- and the x4 logit error 1.3 - 2.2 x larger: DESIGN.md 5b-3).
+// Up to round 4 two cells were updated per packed f32 instruction (lstm_cell2); since round 5 row block rb is updated right behind that row
+// block's MFMAs, one cell at a time with the same operations (every packed instruction was two independent IEEE operations: the logits are
+// bit-identical), so that the update of row blocks 0 .. 2 is issued among the MFMAs of the next one and only ONE cell update -- not a pair --
+// is left exposed behind the last MFMA of a step: 1.815 -> 1.802 ms per launch (A/B, 3 x 4 layers each).
+__device__ __forceinline__ float quot_1(float n, float d) {   // n / d, d in [1, 2^127)
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float q = n * r;
+    return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
 }
-__device__ __forceinline__ void lstm_cell2(const f32x4 ga, const f32x4 gb, float &ca, float &cb, float &ha, float &hb) {
-    const f32x2 one = {1.0f, 1.0f};
-    const f32x2 xi = {ga[0], gb[0]}, xf = {ga[1], gb[1]}, xo = {ga[3], gb[3]};
-    f32x2 ai = xi * -L2E, af = xf * -L2E, ao = xo * -L2E;
-    ai = f32x2{__builtin_fminf(ai[0], 125.0f), __builtin_fminf(ai[1], 125.0f)};
-    af = f32x2{__builtin_fminf(af[0], 125.0f), __builtin_fminf(af[1], 125.0f)};
-    ao = f32x2{__builtin_fminf(ao[0], 125.0f), __builtin_fminf(ao[1], 125.0f)};
-    const f32x2 ag = {(-2.0f * L2E) * __builtin_fabsf(ga[2]), (-2.0f * L2E) * __builtin_fabsf(gb[2])};
-    const f32x2 ei = exp2_2(ai), ef = exp2_2(af), eg = exp2_2(ag), eo = exp2_2(ao);
-    f32x2 itg = quot_2(one - eg, (one + ei) * (one + eg));                      // sigmoid(i) * |tanh(g)|
-    itg = f32x2{__builtin_copysignf(itg[0], ga[2]), __builtin_copysignf(itg[1], gb[2])};
-    const f32x2 fg = quot_2(one, one + ef);
-    const f32x2 c = __builtin_elementwise_fma(fg, f32x2{ca, cb}, itg);
-    ca = c[0];
-    cb = c[1];
-    const f32x2 ec = exp2_2(f32x2{(-2.0f * L2E) * __builtin_fabsf(c[0]), (-2.0f * L2E) * __builtin_fabsf(c[1])});
-    const f32x2 h = quot_2(one - ec, (one + eo) * (one + ec));                  // sigmoid(o) * |tanh(c)|
-    ha = __builtin_copysignf(h[0], c[0]);
-    hb = __builtin_copysignf(h[1], c[1]);
+__device__ __forceinline__ void lstm_cell1(const f32x4 g, float &c, float &h) {
+    const float ai = __builtin_fminf(g[0] * -L2E, 125.0f), af = __builtin_fminf(g[1] * -L2E, 125.0f), ao = __builtin_fminf(g[3] * -L2E, 125.0f);
+    const float ag = (-2.0f * L2E) * __builtin_fabsf(g[2]);
+    const float ei = __builtin_amdgcn_exp2f(ai), ef = __builtin_amdgcn_exp2f(af), eg = __builtin_amdgcn_exp2f(ag), eo = __builtin_amdgcn_exp2f(ao);
+    float itg = quot_1(1.0f - eg, (1.0f + ei) * (1.0f + eg));                        // sigmoid(i) * |tanh(g)|
+    itg = __builtin_copysignf(itg, g[2]);
+    const float fg = quot_1(1.0f, 1.0f + ef);
+    c = __builtin_fmaf(fg, c, itg);
+    const float ec = __builtin_amdgcn_exp2f((-2.0f * L2E) * __builtin_fabsf(c));
+    h = __builtin_copysignf(quot_1(1.0f - ec, (1.0f + eo) * (1.0f + ec)), c);      // sigmoid(o) * |tanh(c)|
 }
 
 // Gate prefetch: plain loads into a ring of PD register slots (the time loop is unrolled by PD so
@@ -453,7 +446,7 @@ __global__ __launch_bounds__(512) void lstm_rec16h_kernel(LstmArgs a) {
             gpre[rb] = __builtin_elementwise_fma(__builtin_elementwise_fma(lo, f32x4{0.00048828125f, 0.00048828125f, 0.00048828125f, 0.00048828125f}, hi),
                                                  f32x4{wscale, wscale, wscale, wscale}, gq[rb]);
             gq[rb] = *reinterpret_cast<const f32x4 *>(gnext + 16 * rb);   // next step's gates of this row block: a whole step to arrive
-            if (rb & 1) lstm_cell2(gpre[rb - 1], gpre[rb], c[rb - 1], c[rb], hnew[rb - 1], hnew[rb]);   // two cells per packed instruction
+            lstm_cell1(gpre[rb], c[rb], hnew[rb]);   // behind its own row block's MFMAs: overlaps the next row block's, one cell exposed at the end
         }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
